@@ -1,0 +1,297 @@
+"""The reference's own known-answer tests, re-expressed against the CPU oracle.
+
+Each test cites the reference test it restates (tests/*.rs under /root/reference).
+These are facts about results (inputs and expected outputs), which is what pins
+the oracle.
+"""
+import ctypes as C
+import itertools
+import math
+
+import numpy as np
+import pytest
+
+from oracle import oracle_lib as ol
+from craytracer_amd import scene as S
+
+L = ol.lib()
+INF = float('inf')
+
+
+def f64(*a):
+    return np.array(a, dtype=np.float64)
+
+
+def shape_intersect(kind, params, origin, direction, tmax=INF):
+    ray = f64(*origin, *direction, tmax)
+    hit = np.zeros(1, dtype=ol.ORC_HIT_DT)
+    params = f64(*params)
+    r = L.orc_shape_intersect(kind, params.ctypes.data, ray.ctypes.data, hit.ctypes.data)
+    return r, hit[0], ray[6]
+
+
+# --- tests/test_bvh.rs:17-67 -------------------------------------------------
+def test_bvh_node():
+    white = S.Material.new_matte(S.Color.WHITE, 0.0)
+    prims = [S.Primitive.new(S.Shape.new_sphere((0.5, 0.5, 0.5), 0.5), white),
+             S.Primitive.new(S.Shape.new_sphere((1.5, 0.5, 0.5), 0.5), white)]
+    cam = S.Camera.perspective(S.Film(4, 4), (0, 0, -5), (0, 0, 0), (0, 1, 0), 60)
+    sc = S.Scene(8, 1, cam, [S.Light.Point((0, 5, 0), S.Color.WHITE)], prims)
+    o = ol.OracleScene(sc, split_method=ol.OracleScene.MEDIAN)
+    rays = [(-1, 0.5, 0.5, 1, 0, 0, INF), (3, 0.5, 0.5, -1, 0, 0, INF),
+            (0.5, 0.5, 0.5, 1, 0, 0, INF), (0.5, 0.5, 0.5, -1, 0, 0, INF)]
+    hits, _ = o.trace(rays)
+    expect = [(0, 0.5, 0.5), (2, 0.5, 0.5), (1, 0.5, 0.5), (0, 0.5, 0.5)]
+    for h, e in zip(hits, expect):
+        assert h['hit'] == 1
+        assert tuple(h['location']) == e  # exact equality, as assert_eq! on Point
+
+
+# --- tests/test_shape.rs:29-61, :64-96 ---------------------------------------
+OFFSETS = [0.0, -1.0, 1.0, 0.001, -0.001, -1e9, 1e9]
+
+
+def test_sphere_intersect_along_axes():
+    radius = 2.0
+    for off in itertools.product(OFFSETS, repeat=3):
+        off = np.array(off)
+        for sign in (1.0, -1.0):
+            for axis in range(3):
+                ray_origin = np.zeros(3)
+                ray_origin[axis] = (radius + 1.0) * sign
+                ray_direction = np.zeros(3) - ray_origin
+                loc = np.zeros(3); loc[axis] = radius * sign
+                nrm = np.zeros(3); nrm[axis] = sign
+                r, hit, _ = shape_intersect(0, (*(np.zeros(3) + off), radius), ray_origin + off, ray_direction)
+                assert r == 1
+                assert tuple(hit['location']) == tuple(loc + off)
+                assert tuple(hit['normal']) == tuple(nrm)
+
+
+def test_sphere_intersect_internal():
+    radius = 2.0
+    for off in itertools.product(OFFSETS, repeat=3):
+        off = np.array(off)
+        for sign in (1.0, -1.0):
+            for axis in range(3):
+                d = np.zeros(3); d[axis] = sign
+                loc = np.zeros(3); loc[axis] = radius * sign
+                nrm = np.zeros(3); nrm[axis] = sign
+                r, hit, _ = shape_intersect(0, (*(np.zeros(3) + off), radius), np.zeros(3) + off, d)
+                assert r == 1
+                assert tuple(hit['location']) == tuple(loc + off)
+                assert tuple(hit['normal']) == tuple(nrm)
+
+
+# --- tests/test_shape.rs:99-109, :132-134 --------------------------------------
+def shape_bounds(kind, params):
+    p = f64(*params); mn = np.zeros(3); mx = np.zeros(3)
+    L.orc_shape_bounds(kind, p.ctypes.data, mn.ctypes.data, mx.ctypes.data)
+    return tuple(mn), tuple(mx)
+
+
+def test_shape_bounds():
+    assert shape_bounds(0, (0, 0, 0, 1.0)) == ((-1, -1, -1), (1, 1, 1))
+    assert shape_bounds(0, (-2, 3, 0, 1.0)) == ((-3, 2, -1), (-1, 4, 1))
+    assert shape_bounds(1, (1, 0, 0, 1, 1, 0, 2, 0, 0)) == ((1, 0, 0), (2, 1, 0))
+
+
+# --- tests/test_shape.rs:137-199 ------------------------------------------------
+TRI = (1, 0, 0, 1, 1, 0, 2, 0, 0)
+
+
+def test_triangle_intersect_vertices():
+    for p in [(1, 0), (1, 1), (2, 0)]:
+        r, hit, tmax = shape_intersect(1, TRI, (p[0], p[1], -2.0), (0, 0, 1))
+        assert r == 1 and tmax == 2.0
+        assert tuple(hit['normal']) == (0, 0, 1)
+
+
+def test_triangle_from_behind():
+    r, hit, tmax = shape_intersect(1, TRI, (1, 0, 2), (-0.0, -0.0, -1.0))
+    assert r == 1 and tmax == 2.0
+    assert tuple(hit['normal']) == (0, 0, 1)
+
+
+def test_triangle_parallel():
+    s = 1 / math.sqrt(2)
+    d = np.array([1.0, 1.0, 0.0]); d = d / math.sqrt(d @ d)
+    r, _, _ = shape_intersect(1, TRI, (0, 0, 0), d)
+    assert r == 0
+
+
+def test_triangle_random_point():
+    rng = np.random.default_rng(7)
+    v0, e1, e2 = np.array([1.0, 0, 0]), np.array([0.0, 1, 0]), np.array([1.0, 0, 0])
+    for _ in range(500):
+        u, v = rng.uniform(0, 1, 2)
+        target = v0 + e1 * u + e2 * v
+        origin = np.array([0.0, 0, -2])
+        d = target - origin
+        dist = math.sqrt(d @ d)
+        r, hit, tmax = shape_intersect(1, TRI, origin, d / dist)
+        if abs(u + v - 1.0) < 1e-12:
+            continue
+        if u + v <= 1.0:
+            assert r == 1 and abs(tmax - dist) <= 1e-9
+            assert tuple(hit['normal']) == (0, 0, 1)
+        else:
+            assert r == 0
+
+
+# --- tests/test_bounds.rs:11-64 ---------------------------------------------------
+def bounds_intersects(mn, mx, o, d):
+    a, b, r = f64(*mn), f64(*mx), f64(*o, *d, INF)
+    return L.orc_bounds_intersects(a.ctypes.data, b.ctypes.data, r.ctypes.data) == 1
+
+
+def test_bounds_intersect_axes():
+    for d in [(1, 0, 0), (-1, -0.0, -0.0), (0, 1, 0), (-0.0, -1, -0.0), (0, 0, 1), (-0.0, -0.0, -1)]:
+        assert bounds_intersects((-1, -1, -1), (1, 1, 1), (0, 0, 0), d)
+
+
+def test_bounds_intersect_random():
+    rng = np.random.default_rng(3)
+    for _ in range(100):
+        target = np.array([-1.0, rng.uniform(-1, 1), rng.uniform(-1, 1)])
+        d = target - np.array([-2.0, 0, 0])
+        assert bounds_intersects((-1, -1, -1), (1, 1, 1), (-2, 0, 0), d / math.sqrt(d @ d))
+
+
+def test_bounds_intersect_miss():
+    # `-X` in Rust is X * -1.0 = (-1, -0, -0) (src/geometry.rs:150-156)
+    assert not bounds_intersects((0, 0, 0), (1, 1, 1), (0, 2, 0), (1, 0, 0))
+    assert not bounds_intersects((0, 0, 0), (1, 1, 1), (0, -2, 0), (-1, -0.0, -0.0))
+    assert not bounds_intersects((0, 0, 0), (1, 1, 1), (2, 0, 0), (0, 1, 0))
+    assert not bounds_intersects((0, 0, 0), (1, 1, 1), (-2, 0, 0), (-0.0, -1, -0.0))
+
+
+# --- tests/test_bxdf.rs:10-25 -------------------------------------------------------
+def test_reflect_refract():
+    s = 1 / math.sqrt(2)
+    d = np.array([-1.0, 1.0, 0.0]); d = d / math.sqrt(d @ d)
+    n = f64(0, 1, 0); out = np.zeros(3)
+    L.orc_reflect(d.ctypes.data, n.ctypes.data, out.ctypes.data)
+    e = np.array([1.0, 1.0, 0.0]); e = e / math.sqrt(e @ e)
+    assert np.all(np.abs(out - e) <= 1e-9)
+    assert L.orc_refract(d.ctypes.data, n.ctypes.data, float(d @ n), 1.0, 1.0, out.ctypes.data) == 1
+    e = np.array([1.0, -1.0, 0.0]); e = e / math.sqrt(e @ e)
+    assert np.all(np.abs(out - e) <= 1e-9)
+
+
+# --- tests/test_transformation.rs ----------------------------------------------------
+def xf(kind, *p):
+    p = f64(*p) if p else np.zeros(1); out = np.zeros(32)
+    L.orc_transformation(kind, p.ctypes.data, out.ctypes.data)
+    return out
+
+
+def apply(t, what, v):
+    v = f64(*v); out = np.zeros(7)
+    L.orc_transform(t.ctypes.data, what, v.ctypes.data, out.ctypes.data)
+    return out[:{0: 3, 1: 3, 2: 3, 3: 7, 4: 6}[what]]
+
+
+def test_matrix_mul_and_inverse():
+    m1 = f64(16, 3, 2, 13, 5, 10, 11, 8, 9, 6, 7, 12, 4, 15, 14, 1)
+    m2 = f64(1, 14, 14, 4, 11, 7, 6, 9, 8, 10, 10, 5, 13, 2, 3, 15)
+    m3 = f64(234, 291, 301, 296, 307, 266, 264, 285, 287, 262, 268, 305, 294, 303, 289, 236)
+    out = np.zeros(16)
+    L.orc_mat_mul(m1.ctypes.data, m2.ctypes.data, out.ctypes.data)
+    assert np.array_equal(out, m3)
+    I = np.eye(4).reshape(-1)
+    L.orc_mat_mul(m1.ctypes.data, I.ctypes.data, out.ctypes.data); assert np.array_equal(out, m1)
+    L.orc_mat_mul(I.ctypes.data, m2.ctypes.data, out.ctypes.data); assert np.array_equal(out, m2)
+
+    m = f64(1, 3, 5, 4, 1, 3, 1, 2, 0, 3, 4, 3, 0, 2, 0, 1)
+    inv = np.zeros(16)
+    assert L.orc_mat_inverse(m.ctypes.data, inv.ctypes.data) == 1
+    e = f64(-1 / 4, 5 / 4, 0, -3 / 2, -1, 1, 1, -1, -3 / 4, 3 / 4, 1, -3 / 2, 2, -2, -2, 3)
+    assert np.all(np.abs(inv - e) <= 1e-9)
+    L.orc_mat_mul(m.ctypes.data, inv.ctypes.data, out.ctypes.data)
+    assert np.array_equal(out, I)  # exact, test_transformation.rs:57
+    sing = f64(1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 1, 0, 0, 0)
+    assert L.orc_mat_inverse(sing.ctypes.data, inv.ctypes.data) == 0
+
+
+def test_translation_scale():
+    t = xf(0, 5.0, -3.0, 2.0)
+    assert tuple(apply(t, 0, (-3, 4, 5))) == (2, 1, 7)
+    assert tuple(apply(t, 1, (-3, 4, 5))) == (-3, 4, 5)
+    assert tuple(apply(t, 2, (-3, 4, 5))) == (-3, 4, 5)
+    assert tuple(apply(t, 3, (-3, 4, 5, 0, 0, 1, INF))) == (2, 1, 7, 0, 0, 1, INF)
+    assert tuple(apply(t, 4, (0, 0, 0, 1, 2, 3))) == (5, -3, 2, 6, -1, 5)
+    t = xf(1, 2.0, -3.0, 0.5)
+    assert tuple(apply(t, 0, (-3, 4, 5))) == (-6, -12, 2.5)
+    assert tuple(apply(t, 1, (-3, 4, 5))) == (-6, -12, 2.5)
+    assert tuple(apply(t, 2, (-3, 4, 5))) == (-3.0 / 2.0, -4.0 / 3.0, 5.0 / 0.5)
+    assert tuple(apply(t, 3, (-3, 4, 5, 0, 0, 1, INF))) == (-6, -12, 2.5, 0, 0, 0.5, INF)
+    assert tuple(apply(t, 4, (0, 0, 0, 1, 2, 3))) == (0, -6, 0, 2, 0, 1.5)
+
+
+def close(a, b):
+    return np.all(np.abs(np.asarray(a) - np.asarray(b)) <= 1e-9)
+
+
+def test_rotations_look_at_perspective():
+    r = math.radians(90.0)
+    t = xf(2, r)
+    for what in (0, 1, 2):
+        assert close(apply(t, what, (2, 1, 3)), (2, -3, 1))
+    assert close(apply(t, 3, (2, 1, 3, 0, 0, 1, INF))[:6], (2, -3, 1, 0, -1, 0))
+    t = xf(3, r)
+    for what in (0, 1, 2):
+        assert close(apply(t, what, (2, 1, 3)), (3, 1, -2))
+    assert close(apply(t, 3, (2, 1, 3, 0, 0, 1, INF))[:6], (3, 1, -2, 1, 0, 0))
+    t = xf(4, r)
+    for what in (0, 1, 2):
+        assert close(apply(t, what, (2, 1, 3)), (-1, 2, 3))
+    assert close(apply(t, 3, (2, 1, 3, 1, 0, 0, INF))[:6], (-1, 2, 3, 0, 1, 0))
+    t = xf(5, 9, 0, 0, 10, 0, 0, 0, 0, 1)
+    assert close(apply(t, 0, (0, 0, 0)), (9, 0, 0))
+    assert close(apply(t, 1, (0, 0, 1)), (1, 0, 0))
+    assert close(apply(t, 1, (0, 1, 0)), (0, 0, 1))
+    assert close(apply(t, 1, (1, 0, 0)), (0, 1, 0))
+    t = xf(6, 90.0, 50.0, 100.0)
+    assert close(apply(t, 0, (0, 0, 50)), (0, 0, 0))
+    assert close(apply(t, 0, (0, 0, 100)), (0, 0, 1))
+    assert close(apply(t, 0, (0, 0, 75)), (0, 0, (100.0 / (100.0 - 50.0)) / (75.0 / (75.0 - 50.0))))
+
+
+# --- tests/test_color.rs:5-19 -----------------------------------------------------------
+def test_color_rgb():
+    out = np.zeros(3)
+    L.orc_color_from_rgb(255, 128, 0, out.ctypes.data)
+    assert tuple(out) == (1.0 ** 2.2, math.pow(128.0 / 255.0, 2.2), 0.0)
+    rgb = np.zeros(3, dtype=np.uint8)
+    L.orc_color_to_rgb(out.ctypes.data, rgb.ctypes.data)
+    assert tuple(rgb) == (255, 128, 0)
+
+
+# --- tests/test_util.rs ---------------------------------------------------------------------
+@pytest.mark.parametrize('data,mode,a,b', [
+    ([], 0, 0, 0), ([1], 1, 7, 0), ([1], 1, 1, 0),
+    ([1, 2, 3], 0, 0, 0), ([1, 2, 3], 0, 1, 0), ([1, 2, 3], 0, 2, 0), ([1, 2, 3], 0, 3, 0),
+    ([1, 2, 3, 4, 5], 1, 2, 0), ([1, 2, 3, 4, 5], 1, 2, 1)])
+def test_partition_by(data, mode, a, b):
+    arr = np.array(data, dtype=np.int64)
+    pred = (lambda x: x > a) if mode == 0 else (lambda x: x % a == b)
+    k = L.orc_partition_by(arr.ctypes.data if len(arr) else None, len(arr), mode, a, b)
+    assert sorted(arr.tolist()) == sorted(data)
+    assert all(pred(x) for x in arr[:k]) and not any(pred(x) for x in arr[k:])
+
+
+# --- third-party arithmetic ------------------------------------------
+def test_siphash_round_function_against_published_vector():
+    # SipHash-2-4 reference vector: key 00..0f, message 00..0e -> a129ca6149be45e5
+    msg = np.arange(15, dtype=np.uint8)
+    k0 = int.from_bytes(bytes(range(8)), 'little'); k1 = int.from_bytes(bytes(range(8, 16)), 'little')
+    assert L.orc_siphash(msg.ctypes.data, 15, k0, k1, 2, 4) == 0xa129ca6149be45e5
+
+
+def test_pixel_hash_is_siphash13_of_three_le_words():
+    for seed, x, y in [(0, 0, 0), (0, 17, 400), (12345, 1919, 1079), (2**40 + 3, 5, 9)]:
+        msg = np.frombuffer(seed.to_bytes(8, 'little') + x.to_bytes(8, 'little') + y.to_bytes(8, 'little'),
+                            dtype=np.uint8).copy()
+        full = L.orc_siphash(msg.ctypes.data, 24, 0, 0, 1, 3)
+        assert L.orc_pixel_hash(seed, x, y) == (full & 0xffffffff)
