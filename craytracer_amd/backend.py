@@ -1,0 +1,246 @@
+"""ctypes binding of the C ABI in include/cray.h and include/cray_host.h.
+
+The product path: scene description -> host `Scene::new` mirror (BVH, light CDF, camera)
+-> cray_scene_upload -> cray_render / cray_trace on the GPU.  There is no CPU fallback: if the
+HIP library is missing or no GPU is visible, these calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class CrayError(RuntimeError):
+    pass
+
+
+class RenderParams(C.Structure):
+    _fields_ = [('seed', C.c_uint64), ('tile_width', C.c_uint32), ('tile_height', C.c_uint32),
+                ('sample_batch', C.c_uint32), ('rank', C.c_uint32), ('world_size', C.c_uint32),
+                ('sample_begin', C.c_uint32), ('sample_end', C.c_uint32), ('out_is_device', C.c_uint32),
+                ('count_traversal', C.c_uint32), ('max_paths_in_flight', C.c_uint64)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in
+                ('paths', 'closest_rays', 'shadow_rays', 'closest_nodes', 'closest_prims', 'shadow_nodes',
+                 'shadow_prims', 'closest_tri_tests', 'shadow_tri_tests', 'nonfinite', 'stack_overflow')] + \
+               [(n, C.c_double) for n in ('seconds', 'trace_closest_ms', 'trace_any_ms', 'shade_ms', 'other_ms')] + \
+               [(n, C.c_uint32) for n in ('trace_closest_launches', 'trace_any_launches', 'shade_launches', 'pad_')]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != 'pad_'}
+
+
+RAY_DT = np.dtype([('o', '<f8', 3), ('d', '<f8', 3), ('tmax', '<f8')], align=True)
+HIT_DT = np.dtype([('hit', '<i4'), ('prim', '<i4'), ('t', '<f8'), ('location', '<f8', 3), ('normal', '<f8', 3),
+                   ('uv', '<f8', 2)], align=True)
+BVH_NODE_DT = np.dtype([('bmin', '<f8', 3), ('bmax', '<f8', 3), ('left', '<u4'), ('right', '<u4'), ('first', '<u4'),
+                        ('count', '<u4'), ('axis', '<i4'), ('is_leaf', '<i4')], align=True)
+assert RAY_DT.itemsize == 56 and HIT_DT.itemsize == 80 and BVH_NODE_DT.itemsize == 72
+
+
+class FlatScene(C.Structure):
+    _fields_ = [('abi_version', C.c_uint32), ('max_depth', C.c_uint32), ('num_samples', C.c_uint32),
+                ('camera_type', C.c_int32), ('film_width', C.c_uint32), ('film_height', C.c_uint32),
+                ('camera_from_raster', C.c_double * 16), ('world_from_camera', C.c_double * 16),
+                ('lens_radius', C.c_double), ('focal_distance', C.c_double),
+                ('n_nodes', C.c_uint32), ('nodes', C.c_void_p),
+                ('n_prim_refs', C.c_uint32), ('prim_refs', C.c_void_p),
+                ('n_prims', C.c_uint32), ('prims', C.c_void_p),
+                ('n_triangles', C.c_uint32), ('triangles', C.c_void_p),
+                ('n_spheres', C.c_uint32), ('spheres', C.c_void_p),
+                ('n_disks', C.c_uint32), ('disks', C.c_void_p),
+                ('n_materials', C.c_uint32), ('materials', C.c_void_p),
+                ('n_bxdfs', C.c_uint32), ('bxdfs', C.c_void_p),
+                ('n_textures', C.c_uint32), ('textures', C.c_void_p),
+                ('n_images', C.c_uint32), ('images', C.c_void_p),
+                ('image_pool_bytes', C.c_uint64), ('image_pool', C.c_void_p),
+                ('n_lights', C.c_uint32), ('lights', C.c_void_p),
+                ('light_cdf', C.c_void_p), ('first_equal_light', C.c_void_p)]
+
+
+#: every symbol include/cray.h and include/cray_host.h declare
+ABI_SYMBOLS = ['cray_ctx_create', 'cray_ctx_destroy', 'cray_scene_upload', 'cray_scene_free',
+               'cray_scene_device_bytes', 'cray_render', 'cray_render_params_default', 'cray_render_samples',
+               'cray_trace', 'cray_last_error', 'cray_host_scene_new', 'cray_host_scene_flat',
+               'cray_host_scene_build_seconds', 'cray_host_scene_free']
+
+_lib = None
+
+
+def lib():
+    """Load libcray_hip.so (building it if the sources are newer). Raises if it cannot be loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    so = _build.SO
+    if _build.stale():
+        try:
+            _build.build()
+        except Exception as e:  # no hipcc on this box: use the shipped .so if there is one
+            if not os.path.exists(so):
+                raise CrayError('libcray_hip.so is missing and could not be built: %s' % e)
+    try:
+        L = C.CDLL(so)
+    except OSError as e:
+        raise CrayError('cannot load %s: %s (the HIP backend has no CPU fallback)' % (so, e))
+    L.cray_last_error.restype = C.c_char_p
+    L.cray_ctx_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.cray_ctx_destroy.argtypes = [C.c_void_p]
+    L.cray_scene_upload.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.cray_scene_free.argtypes = [C.c_void_p]
+    L.cray_scene_device_bytes.restype = C.c_uint64
+    L.cray_scene_device_bytes.argtypes = [C.c_void_p]
+    L.cray_render.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]
+    L.cray_render_params_default.argtypes = [C.POINTER(RenderParams)]
+    L.cray_render_samples.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(RenderParams), C.c_void_p]
+    L.cray_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.POINTER(Stats)]
+    L.cray_host_scene_new.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    L.cray_host_scene_flat.restype = C.POINTER(FlatScene)
+    L.cray_host_scene_flat.argtypes = [C.c_void_p]
+    L.cray_host_scene_build_seconds.restype = C.c_double
+    L.cray_host_scene_build_seconds.argtypes = [C.c_void_p]
+    L.cray_host_scene_free.argtypes = [C.c_void_p]
+    _lib = L
+    return L
+
+
+def _check(code, what):
+    if code != 0:
+        raise CrayError('%s failed (%d): %s' % (what, code, lib().cray_last_error().decode()))
+
+
+class HostScene:
+    """`Scene::new` on the host (src/scene.rs:25-53): BVH (SAH), LightSampler, Camera matrices."""
+
+    SAH, MEDIAN = 1, 0
+
+    def __init__(self, scene, split_method=1):
+        self.scene = scene  # keeps the description arrays alive (the flat view borrows them)
+        h = C.c_void_p()
+        _check(lib().cray_host_scene_new(C.addressof(scene.desc()), split_method, C.byref(h)), 'cray_host_scene_new')
+        self._h = h
+        self.flat = lib().cray_host_scene_flat(h).contents
+        self.build_seconds = lib().cray_host_scene_build_seconds(h)
+
+    def bvh(self):
+        n, m = self.flat.n_nodes, self.flat.n_prim_refs
+        nodes = np.ctypeslib.as_array(C.cast(self.flat.nodes, C.POINTER(C.c_uint8)), shape=(n * 72,)).view(BVH_NODE_DT)
+        refs = np.ctypeslib.as_array(C.cast(self.flat.prim_refs, C.POINTER(C.c_uint32)), shape=(m,))
+        return nodes.copy(), refs.copy()
+
+    def light_cdf(self):
+        return np.ctypeslib.as_array(C.cast(self.flat.light_cdf, C.POINTER(C.c_double)),
+                                     shape=(self.flat.n_lights,)).copy()
+
+    def first_equal_light(self):
+        return np.ctypeslib.as_array(C.cast(self.flat.first_equal_light, C.POINTER(C.c_int32)),
+                                     shape=(self.flat.n_lights,)).copy()
+
+    def camera_matrices(self):
+        return (np.array(self.flat.camera_from_raster[:]).reshape(4, 4),
+                np.array(self.flat.world_from_camera[:]).reshape(4, 4))
+
+    def close(self):
+        if self._h:
+            lib().cray_host_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    """One GPU (one process per GPU)."""
+
+    def __init__(self, device=0, stream=None):
+        h = C.c_void_p()
+        _check(lib().cray_ctx_create(device, stream, C.byref(h)), 'cray_ctx_create')
+        self._h = h
+        self.device = device
+
+    def upload(self, host_scene):
+        return DeviceScene(self, host_scene)
+
+    def close(self):
+        if self._h:
+            lib().cray_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceScene:
+    """A scene resident in HBM; `render` replaces craytracer.rs:224 `render`, `trace` replaces
+    `Scene::intersect` / `Scene::intersects`."""
+
+    def __init__(self, ctx, host_scene):
+        self.ctx, self.host = ctx, host_scene
+        h = C.c_void_p()
+        _check(lib().cray_scene_upload(ctx._h, C.addressof(host_scene.flat), C.byref(h)), 'cray_scene_upload')
+        self._h = h
+        self.width, self.height = host_scene.flat.film_width, host_scene.flat.film_height
+        self.num_samples = host_scene.flat.num_samples
+        self.device_bytes = lib().cray_scene_device_bytes(h)
+
+    def params(self, seed=0, rank=0, world_size=1, sample_range=None, count_traversal=False, max_paths_in_flight=0):
+        p = RenderParams()
+        lib().cray_render_params_default(C.byref(p))
+        p.seed, p.rank, p.world_size = seed, rank, world_size
+        if sample_range is not None:
+            p.sample_begin, p.sample_end = sample_range
+        p.count_traversal = 1 if count_traversal else 0
+        p.max_paths_in_flight = max_paths_in_flight
+        return p
+
+    def render(self, seed=0, rank=0, world_size=1, sample_range=None, count_traversal=False, max_paths_in_flight=0,
+               out_device_ptr=None):
+        """Returns (film[h, w, 3] float32 or None when writing to out_device_ptr, stats dict)."""
+        p = self.params(seed, rank, world_size, sample_range, count_traversal, max_paths_in_flight)
+        st = Stats()
+        if out_device_ptr is not None:
+            p.out_is_device = 1
+            _check(lib().cray_render(self.ctx._h, self._h, C.byref(p), C.c_void_p(out_device_ptr), C.byref(st)), 'cray_render')
+            return None, st.as_dict()
+        out = np.zeros((self.height, self.width, 3), dtype=np.float32)
+        _check(lib().cray_render(self.ctx._h, self._h, C.byref(p), out.ctypes.data, C.byref(st)), 'cray_render')
+        return out, st.as_dict()
+
+    def render_samples(self, sample_range, seed=0):
+        """Per-path radiance L[h, w, n, 3] (f64) of samples [a, b)."""
+        p = self.params(seed, sample_range=sample_range)
+        n = sample_range[1] - sample_range[0]
+        out = np.zeros((self.height, self.width, n, 3), dtype=np.float64)
+        _check(lib().cray_render_samples(self.ctx._h, self._h, C.byref(p), out.ctypes.data), 'cray_render_samples')
+        return out
+
+    def trace(self, rays, any_hit=False):
+        rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 7)
+        hits = np.zeros(len(rays), dtype=HIT_DT)
+        st = Stats()
+        _check(lib().cray_trace(self.ctx._h, self._h, rays.ctypes.data, len(rays), hits.ctypes.data,
+                                1 if any_hit else 0, C.byref(st)), 'cray_trace')
+        return hits, st.as_dict()
+
+    def close(self):
+        if self._h:
+            lib().cray_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

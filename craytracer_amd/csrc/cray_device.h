@@ -1,0 +1,117 @@
+// cray_device.h — device-side data layout in HBM and the per-path state (SoA).
+//
+// Layout decisions (DESIGN.md "Data layout in HBM"):
+//  * BVH: one 128-byte record per *interior* node holding BOTH children's bounds, so
+//    one dependent 128-B (one cache line) fetch yields two slab tests.  Leaves have no
+//    record: a child reference with the top bit set encodes (first leaf slot, count).
+//  * Triangles are re-ordered into leaf order ("slots"); a slot is one 80-byte record
+//    (v0,e1,e2 + primitive id) = five 16-B loads per lane.
+//  * Shading data (normals / uvs) stays in primitive order, touched once per closest hit.
+//  * Path state is SoA over path slots so that wave loads are coalesced.
+#pragma once
+
+#include "../../include/cray.h"
+#include "cray_math.h"
+
+namespace cray {
+
+constexpr uint32_t kLeafBit = 0x80000000u;
+constexpr uint32_t kNoRef = 0xffffffffu;
+constexpr int kStackDepth = 96;
+
+// child reference: interior -> index into DevScene::inner;
+// leaf -> kLeafBit | first_slot << 3 | (count - 1), count in 1..8
+CRAY_HD bool ref_is_leaf(uint32_t r) { return (r & kLeafBit) != 0; }
+CRAY_HD uint32_t ref_leaf_first(uint32_t r) { return (r & ~kLeafBit) >> 3; }
+CRAY_HD uint32_t ref_leaf_count(uint32_t r) { return (r & 7u) + 1u; }
+
+struct alignas(128) InnerNode {
+    double lo0[3], hi0[3];  // left child's Bounds
+    double lo1[3], hi1[3];  // right child's Bounds
+    uint32_t ref0, ref1;    // left / right child reference
+    uint32_t axis;          // split axis of THIS node (orders the children, bvh.rs:92-98)
+    uint32_t pad_;
+    double pad2_[2];
+};
+static_assert(sizeof(InnerNode) == 128, "InnerNode must be one 128-B line");
+
+struct alignas(16) LeafSlot {
+    double v0[3], e1[3], e2[3];  // Shape::Triangle geometry (zeros for sphere / disk slots)
+    uint32_t prim;               // index into prims[]
+    uint32_t kind;               // CRAY_SHAPE_*
+};
+static_assert(sizeof(LeafSlot) == 80, "LeafSlot is five 16-B loads");
+
+struct TriShade {
+    double n0[3], n01[3], n02[3];
+    double uv0[2], uv01[2], uv02[2];
+};
+
+// One entry per light; area lights carry their own shape's geometry so that
+// Shape::sample / Shape::pdf_from need no second lookup (src/light.rs:114-131, shape.rs:445-514).
+struct DevLight {
+    int32_t kind;        // CRAY_LIGHT_*
+    int32_t shape_kind;  // area lights: CRAY_SHAPE_*
+    uint32_t shape;      // index into spheres[] / disks[]
+    uint32_t pad_;
+    double v[3];         // Point origin / Distant direction
+    double c[3];         // intensity / emittance
+    double v0[3], e1[3], e2[3];  // triangle emitters
+    double area;         // Shape::area() (sphere: PI r^2 as in the reference, shape.rs:506)
+};
+
+struct DevScene {
+    // Scene / Camera
+    uint32_t max_depth, num_samples, film_w, film_h;
+    int32_t camera_type;
+    uint32_t n_lights;
+    double lens_radius, focal_distance;
+    double camera_from_raster[16], world_from_camera[16];
+    // BVH
+    double root_lo[3], root_hi[3];
+    uint32_t root_ref, n_inner;
+    const InnerNode* inner;
+    const LeafSlot* slots;
+    // primitives
+    const cray_prim* prims;
+    const TriShade* tri_shade;  // indexed by prims[].shape for triangles
+    const cray_xf_shape* spheres;
+    const cray_xf_shape* disks;
+    // materials
+    const cray_material* materials;
+    const cray_bxdf* bxdfs;
+    const cray_texture* textures;
+    const cray_image* images;
+    const uint8_t* pool;
+    const double* gamma_lut;  // (c/255)^2.2 for c in 0..255 (Color::from_rgb, color.rs:39-46)
+    // lights
+    const DevLight* lights;
+    const double* light_cdf;
+    const int32_t* first_equal_light;
+    // sampler
+    const uint16_t* sobol;  // [64][16][4] bit-reversed direction vectors
+};
+
+// Per-path state, SoA over `capacity` path slots.
+struct PathState {
+    double *ox, *oy, *oz, *dx, *dy, *dz;   // current ray (tmax is +inf for path segments)
+    double *br, *bg, *bb;                  // beta
+    double *lr, *lg, *lb;                  // L
+    double* prev_pdf;                      // prev_bsdf_pdf
+    double *ht, *hu, *hv;                  // closest hit: distance, triangle barycentrics
+    int32_t* hprim;                        // closest hit primitive (-1 = miss)
+    double *sox, *soy, *soz, *sdx, *sdy, *sdz, *stmax;  // shadow ray
+    double *cr, *cg, *cb;                  // NEE contribution added if the shadow ray is unoccluded
+    uint32_t* hash;                        // per-pixel Sobol seed (SipHash-1-3)
+    uint32_t* flags;                       // bit0: is_specular_bounce
+};
+
+struct Counters {
+    unsigned long long closest_rays, shadow_rays;
+    unsigned long long closest_nodes, closest_prims, shadow_nodes, shadow_prims;
+    unsigned long long closest_tri, shadow_tri;
+    unsigned long long nonfinite, stack_overflow;
+    unsigned int n_active[2], n_shadow, pad_;
+};
+
+}  // namespace cray

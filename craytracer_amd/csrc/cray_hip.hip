@@ -1,0 +1,651 @@
+// cray_hip.hip — runtime and C ABI (include/cray.h) of the MI355X render backend.
+//
+// Host side of the wavefront loop: uploads the flattened scene in the device layout,
+// then for every pass (a block of pixels x sample batches that fits the path-state
+// buffers) runs   raygen ; { trace_closest ; shade ; trace_any } x max_depth ; film
+// on one HIP stream without any host round trip: queue lengths live in device memory and
+// the kernels read them, so a whole frame is a fixed launch sequence.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "cray_kernels.h"
+#include "sobol_rev_vectors.h"
+
+namespace cray {
+
+static thread_local char g_err[512] = "";
+void set_last_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            set_last_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return CRAY_ERR_HIP;                                                                   \
+        }                                                                                          \
+    } while (0)
+
+struct DeviceBuffer {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace cray
+
+using namespace cray;
+
+struct cray_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int n_cu = 256;
+    // path-state pool
+    size_t capacity = 0;
+    std::vector<void*> state_allocs;
+    PathState ps{};
+    uint32_t* queue[2] = {nullptr, nullptr};
+    uint32_t* shadow_queue = nullptr;
+    Counters* counters = nullptr;
+    uint32_t* pix_list = nullptr;
+    size_t pix_capacity = 0;
+    float* film = nullptr;
+    size_t film_floats = 0;
+    // event pool for per-family kernel timing
+    std::vector<hipEvent_t> events;
+};
+
+struct cray_scene {
+    cray_ctx* ctx = nullptr;
+    DevScene dev{};
+    std::vector<void*> allocs;
+    uint64_t bytes = 0;
+    uint32_t n_prims = 0;
+};
+
+namespace {
+
+template <class T>
+int upload(cray_scene* s, const T* host, size_t n, const T** out) {
+    *out = nullptr;
+    size_t bytes = n * sizeof(T);
+    if (bytes == 0) bytes = sizeof(T);  // keep a valid pointer for empty tables
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, bytes));
+    s->allocs.push_back(d);
+    s->bytes += bytes;
+    if (n) HIP_TRY(hipMemcpy(d, host, n * sizeof(T), hipMemcpyHostToDevice));
+    *out = (const T*)d;
+    return CRAY_OK;
+}
+
+int ensure_state(cray_ctx* c, size_t capacity) {
+    if (c->capacity >= capacity) return CRAY_OK;
+    for (void* p : c->state_allocs) hipFree(p);
+    c->state_allocs.clear();
+    c->capacity = 0;
+    auto alloc = [&](size_t bytes, void** out) -> int {
+        HIP_TRY(hipMalloc(out, bytes));
+        c->state_allocs.push_back(*out);
+        return CRAY_OK;
+    };
+    double** f64s[] = {&c->ps.ox, &c->ps.oy, &c->ps.oz, &c->ps.dx, &c->ps.dy, &c->ps.dz, &c->ps.br, &c->ps.bg, &c->ps.bb,
+                       &c->ps.lr, &c->ps.lg, &c->ps.lb, &c->ps.prev_pdf, &c->ps.ht, &c->ps.hu, &c->ps.hv,
+                       &c->ps.sox, &c->ps.soy, &c->ps.soz, &c->ps.sdx, &c->ps.sdy, &c->ps.sdz, &c->ps.stmax,
+                       &c->ps.cr, &c->ps.cg, &c->ps.cb};
+    for (double** f : f64s) {
+        int r = alloc(capacity * sizeof(double), (void**)f);
+        if (r) return r;
+    }
+    int r;
+    if ((r = alloc(capacity * 4, (void**)&c->ps.hprim))) return r;
+    if ((r = alloc(capacity * 4, (void**)&c->ps.hash))) return r;
+    if ((r = alloc(capacity * 4, (void**)&c->ps.flags))) return r;
+    if ((r = alloc(capacity * 4, (void**)&c->queue[0]))) return r;
+    if ((r = alloc(capacity * 4, (void**)&c->queue[1]))) return r;
+    if ((r = alloc(capacity * 4, (void**)&c->shadow_queue))) return r;
+    c->capacity = capacity;
+    return CRAY_OK;
+}
+
+struct EventTimer {
+    cray_ctx* c;
+    size_t used = 0;
+    struct Span { size_t a, b; int family; };
+    std::vector<Span> spans;
+    explicit EventTimer(cray_ctx* ctx) : c(ctx) {}
+    int begin(int family) {
+        while (c->events.size() < used + 2) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            c->events.push_back(e);
+        }
+        HIP_TRY(hipEventRecord(c->events[used], c->stream));
+        spans.push_back(Span{used, used + 1, family});
+        used += 2;
+        return CRAY_OK;
+    }
+    int end() {
+        HIP_TRY(hipEventRecord(c->events[spans.back().b], c->stream));
+        return CRAY_OK;
+    }
+    int collect(double ms[4], uint32_t launches[4]) {
+        for (int i = 0; i < 4; i++) { ms[i] = 0.0; launches[i] = 0; }
+        for (const Span& s : spans) {
+            float t = 0.f;
+            HIP_TRY(hipEventElapsedTime(&t, c->events[s.a], c->events[s.b]));
+            ms[s.family] += t;
+            launches[s.family] += 1;
+        }
+        return CRAY_OK;
+    }
+};
+enum { FAM_CLOSEST = 0, FAM_ANY = 1, FAM_SHADE = 2, FAM_OTHER = 3 };
+
+int grid_for(const cray_ctx* c, size_t n, int blocks_per_cu) {
+    size_t want = (n + kBlock - 1) / kBlock;
+    size_t cap = (size_t)c->n_cu * blocks_per_cu;
+    if (want < 1) want = 1;
+    return (int)(want < cap ? want : cap);
+}
+
+void fill_stats(const Counters& h, cray_stats* st) {
+    st->closest_rays = h.closest_rays; st->shadow_rays = h.shadow_rays;
+    st->closest_nodes = h.closest_nodes; st->closest_prims = h.closest_prims;
+    st->shadow_nodes = h.shadow_nodes; st->shadow_prims = h.shadow_prims;
+    st->closest_tri_tests = h.closest_tri; st->shadow_tri_tests = h.shadow_tri;
+    st->nonfinite = h.nonfinite; st->stack_overflow = h.stack_overflow;
+}
+
+}  // namespace
+
+extern "C" const char* cray_last_error(void) { return g_err; }
+
+extern "C" int cray_ctx_create(int device_id, void* stream, cray_ctx** out) {
+    if (!out) { set_last_error("cray_ctx_create: out is null"); return CRAY_ERR_INVALID; }
+    *out = nullptr;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) {
+        set_last_error("no HIP device visible: this backend has no CPU fallback");
+        return CRAY_ERR_NO_DEVICE;
+    }
+    if (device_id < 0 || device_id >= n_dev) { set_last_error("device %d out of range (%d devices)", device_id, n_dev); return CRAY_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(device_id));
+    cray_ctx* c = new cray_ctx();
+    c->device = device_id;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    HIP_TRY(hipMalloc((void**)&c->counters, sizeof(Counters)));
+    *out = c;
+    return CRAY_OK;
+}
+
+extern "C" void cray_ctx_destroy(cray_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    for (void* p : c->state_allocs) hipFree(p);
+    if (c->counters) hipFree(c->counters);
+    if (c->pix_list) hipFree(c->pix_list);
+    if (c->film) hipFree(c->film);
+    for (hipEvent_t e : c->events) hipEventDestroy(e);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" void cray_scene_free(cray_scene* s) {
+    if (!s) return;
+    if (s->ctx) hipSetDevice(s->ctx->device);
+    for (void* p : s->allocs) hipFree(p);
+    delete s;
+}
+extern "C" uint64_t cray_scene_device_bytes(const cray_scene* s) { return s ? s->bytes : 0; }
+
+// Flattened reference-topology BVH -> device layout (cray_device.h).
+extern "C" int cray_scene_upload(cray_ctx* c, const cray_flat_scene* f, cray_scene** out) {
+    if (!c || !f || !out) { set_last_error("cray_scene_upload: null argument"); return CRAY_ERR_INVALID; }
+    *out = nullptr;
+    if (f->abi_version != CRAY_ABI_VERSION) { set_last_error("flat scene abi_version %u != %u", f->abi_version, CRAY_ABI_VERSION); return CRAY_ERR_INVALID; }
+    if (f->n_nodes == 0 || f->n_prims == 0 || f->n_lights == 0) { set_last_error("scene needs nodes, primitives and lights"); return CRAY_ERR_INVALID; }
+    if (4 + 8 * (uint64_t)f->max_depth > 256) { set_last_error("max_depth %u needs more than sobol_burley's 256 dimensions", f->max_depth); return CRAY_ERR_UNSUPPORTED; }
+    if (f->n_prims >= (1u << 28)) { set_last_error("too many primitives for the 28-bit leaf slot index"); return CRAY_ERR_UNSUPPORTED; }
+    HIP_TRY(hipSetDevice(c->device));
+
+    // ---- leaf slots in leaf order; interior records with both children's bounds
+    std::vector<LeafSlot> slots(f->n_prim_refs);
+    for (uint32_t i = 0; i < f->n_prim_refs; i++) {
+        uint32_t pi = f->prim_refs[i];
+        if (pi >= f->n_prims) { set_last_error("prim_refs[%u] out of range", i); return CRAY_ERR_INVALID; }
+        const cray_prim& p = f->prims[pi];
+        LeafSlot& s = slots[i];
+        memset(&s, 0, sizeof(s));
+        s.prim = pi;
+        s.kind = (uint32_t)p.shape_kind;
+        if (p.shape_kind == CRAY_SHAPE_TRIANGLE) {
+            if (p.shape >= f->n_triangles) { set_last_error("primitive %u: bad triangle index", pi); return CRAY_ERR_INVALID; }
+            const cray_triangle& t = f->triangles[p.shape];
+            s.v0[0] = t.v0.x; s.v0[1] = t.v0.y; s.v0[2] = t.v0.z;
+            s.e1[0] = t.e1.x; s.e1[1] = t.e1.y; s.e1[2] = t.e1.z;
+            s.e2[0] = t.e2.x; s.e2[1] = t.e2.y; s.e2[2] = t.e2.z;
+        } else if ((p.shape_kind == CRAY_SHAPE_SPHERE && p.shape >= f->n_spheres) || (p.shape_kind == CRAY_SHAPE_DISK && p.shape >= f->n_disks) ||
+                   (p.shape_kind != CRAY_SHAPE_SPHERE && p.shape_kind != CRAY_SHAPE_DISK)) {
+            set_last_error("primitive %u: bad shape", pi);
+            return CRAY_ERR_INVALID;
+        }
+    }
+    std::vector<uint32_t> inner_index(f->n_nodes, kNoRef);
+    uint32_t n_inner = 0;
+    for (uint32_t i = 0; i < f->n_nodes; i++)
+        if (!f->nodes[i].is_leaf) inner_index[i] = n_inner++;
+    auto make_ref = [&](uint32_t node, uint32_t* ref) -> int {
+        if (node >= f->n_nodes) { set_last_error("BVH child index %u out of range", node); return CRAY_ERR_INVALID; }
+        const cray_bvh_node& nd = f->nodes[node];
+        if (!nd.is_leaf) { *ref = inner_index[node]; return CRAY_OK; }
+        if (nd.count < 1 || nd.count > 8) { set_last_error("BVH leaf with %u primitives (supported: 1..8)", nd.count); return CRAY_ERR_UNSUPPORTED; }
+        if ((uint64_t)nd.first + nd.count > f->n_prim_refs) { set_last_error("BVH leaf range out of bounds"); return CRAY_ERR_INVALID; }
+        *ref = kLeafBit | (nd.first << 3) | (nd.count - 1);
+        return CRAY_OK;
+    };
+    std::vector<InnerNode> inner(n_inner ? n_inner : 1);
+    memset(inner.data(), 0, inner.size() * sizeof(InnerNode));
+    for (uint32_t i = 0; i < f->n_nodes; i++) {
+        const cray_bvh_node& nd = f->nodes[i];
+        if (nd.is_leaf) continue;
+        if (nd.left >= f->n_nodes || nd.right >= f->n_nodes || nd.axis < 0 || nd.axis > 2) { set_last_error("BVH node %u malformed", i); return CRAY_ERR_INVALID; }
+        InnerNode& o = inner[inner_index[i]];
+        const cray_bvh_node& l = f->nodes[nd.left];
+        const cray_bvh_node& r = f->nodes[nd.right];
+        for (int k = 0; k < 3; k++) { o.lo0[k] = l.bmin[k]; o.hi0[k] = l.bmax[k]; o.lo1[k] = r.bmin[k]; o.hi1[k] = r.bmax[k]; }
+        int e;
+        if ((e = make_ref(nd.left, &o.ref0))) return e;
+        if ((e = make_ref(nd.right, &o.ref1))) return e;
+        o.axis = (uint32_t)nd.axis;
+    }
+
+    cray_scene* s = new cray_scene();
+    s->ctx = c;
+    s->n_prims = f->n_prims;
+    DevScene& d = s->dev;
+    d.max_depth = f->max_depth; d.num_samples = f->num_samples;
+    d.film_w = f->film_width; d.film_h = f->film_height;
+    d.camera_type = f->camera_type; d.n_lights = f->n_lights;
+    d.lens_radius = f->lens_radius; d.focal_distance = f->focal_distance;
+    memcpy(d.camera_from_raster, f->camera_from_raster, sizeof(d.camera_from_raster));
+    memcpy(d.world_from_camera, f->world_from_camera, sizeof(d.world_from_camera));
+    for (int k = 0; k < 3; k++) { d.root_lo[k] = f->nodes[0].bmin[k]; d.root_hi[k] = f->nodes[0].bmax[k]; }
+    int e = make_ref(0, &d.root_ref);
+    d.n_inner = n_inner;
+
+    // triangle shading records, in triangle-table order
+    std::vector<TriShade> shade(f->n_triangles);
+    for (uint32_t i = 0; i < f->n_triangles; i++) {
+        const cray_triangle& t = f->triangles[i];
+        TriShade& o = shade[i];
+        o.n0[0] = t.n0.x; o.n0[1] = t.n0.y; o.n0[2] = t.n0.z;
+        o.n01[0] = t.n01.x; o.n01[1] = t.n01.y; o.n01[2] = t.n01.z;
+        o.n02[0] = t.n02.x; o.n02[1] = t.n02.y; o.n02[2] = t.n02.z;
+        for (int k = 0; k < 2; k++) { o.uv0[k] = t.uv0[k]; o.uv01[k] = t.uv01[k]; o.uv02[k] = t.uv02[k]; }
+    }
+    // lights with their emitter geometry and Shape::area (shape.rs:504-514)
+    std::vector<DevLight> lights(f->n_lights);
+    for (uint32_t i = 0; i < f->n_lights && !e; i++) {
+        const cray_light& l = f->lights[i];
+        DevLight& o = lights[i];
+        memset(&o, 0, sizeof(o));
+        o.kind = l.kind;
+        o.v[0] = l.v.x; o.v[1] = l.v.y; o.v[2] = l.v.z;
+        o.c[0] = l.c.r; o.c[1] = l.c.g; o.c[2] = l.c.b;
+        if (l.kind != CRAY_LIGHT_AREA) continue;
+        if (l.prim < 0 || (uint32_t)l.prim >= f->n_prims) { set_last_error("area light %u: bad primitive", i); e = CRAY_ERR_INVALID; break; }
+        const cray_prim& p = f->prims[l.prim];
+        o.shape_kind = p.shape_kind; o.shape = p.shape;
+        if (p.shape_kind == CRAY_SHAPE_TRIANGLE) {
+            const cray_triangle& t = f->triangles[p.shape];
+            o.v0[0] = t.v0.x; o.v0[1] = t.v0.y; o.v0[2] = t.v0.z;
+            o.e1[0] = t.e1.x; o.e1[1] = t.e1.y; o.e1[2] = t.e1.z;
+            o.e2[0] = t.e2.x; o.e2[1] = t.e2.y; o.e2[2] = t.e2.z;
+            o.area = len(cross(mk(t.e1.x, t.e1.y, t.e1.z), mk(t.e2.x, t.e2.y, t.e2.z))) / 2.0;
+        } else if (p.shape_kind == CRAY_SHAPE_SPHERE) {
+            o.area = kPi * square(f->spheres[p.shape].radius);
+        } else {
+            o.area = kPi * (square(f->disks[p.shape].radius) - square(f->disks[p.shape].inner_radius));
+        }
+    }
+    for (uint32_t i = 0; i < f->n_prims && !e; i++) {
+        const cray_prim& p = f->prims[i];
+        if (p.material >= (int32_t)f->n_materials || p.light >= (int32_t)f->n_lights || (p.material < 0 && p.light < 0)) {
+            set_last_error("primitive %u: bad material/light index", i);
+            e = CRAY_ERR_INVALID;
+        }
+    }
+    double gamma_lut[256];  // Color::from_rgb (color.rs:39-46): (c/255).powf(2.2), libm pow like the reference
+    for (int i = 0; i < 256; i++) gamma_lut[i] = pow((double)i / 255.0, 2.2);
+
+    if (!e) e = upload(s, inner.data(), inner.size(), &d.inner);
+    if (!e) e = upload(s, slots.data(), slots.size(), &d.slots);
+    if (!e) e = upload(s, f->prims, (size_t)f->n_prims, &d.prims);
+    if (!e) e = upload(s, shade.data(), shade.size(), &d.tri_shade);
+    if (!e) e = upload(s, f->spheres, (size_t)f->n_spheres, &d.spheres);
+    if (!e) e = upload(s, f->disks, (size_t)f->n_disks, &d.disks);
+    if (!e) e = upload(s, f->materials, (size_t)f->n_materials, &d.materials);
+    if (!e) e = upload(s, f->bxdfs, (size_t)f->n_bxdfs, &d.bxdfs);
+    if (!e) e = upload(s, f->textures, (size_t)f->n_textures, &d.textures);
+    if (!e) e = upload(s, f->images, (size_t)f->n_images, &d.images);
+    if (!e) e = upload(s, f->image_pool, (size_t)f->image_pool_bytes, &d.pool);
+    if (!e) e = upload(s, gamma_lut, (size_t)256, &d.gamma_lut);
+    if (!e) e = upload(s, lights.data(), lights.size(), &d.lights);
+    if (!e) e = upload(s, f->light_cdf, (size_t)f->n_lights, &d.light_cdf);
+    if (!e) e = upload(s, f->first_equal_light, (size_t)f->n_lights, &d.first_equal_light);
+    if (!e) e = upload(s, &CRAY_SOBOL_REV_VECTORS[0][0][0], (size_t)CRAY_SOBOL_SETS * CRAY_SOBOL_BITS * 4, &d.sobol);
+    if (e) { cray_scene_free(s); return e; }
+    *out = s;
+    return CRAY_OK;
+}
+
+extern "C" void cray_render_params_default(cray_render_params* p) {
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->tile_width = 64; p->tile_height = 64; p->sample_batch = 8;  // craytracer.rs:232-234
+    p->rank = 0; p->world_size = 1;
+}
+
+namespace {
+
+struct PassPlan { uint32_t px0, n_pix, s_lo, s_hi; };
+
+// pixels of the tiles this rank owns (tile_index % world == rank), tile by tile, row-major inside
+// a tile; tiles are numbered like generate_tiles (craytracer.rs:32-33): ty outer, tx inner.
+std::vector<uint32_t> rank_pixels(uint32_t W, uint32_t H, const cray_render_params& p) {
+    std::vector<uint32_t> pix;
+    uint32_t tiles_x = (W + p.tile_width - 1) / p.tile_width, tiles_y = (H + p.tile_height - 1) / p.tile_height;
+    for (uint32_t t = p.rank; t < tiles_x * tiles_y; t += p.world_size) {
+        uint32_t tx = (t % tiles_x) * p.tile_width, ty = (t / tiles_x) * p.tile_height;
+        uint32_t x1 = tx + p.tile_width < W ? tx + p.tile_width : W, y1 = ty + p.tile_height < H ? ty + p.tile_height : H;
+        for (uint32_t y = ty; y < y1; y++)
+            for (uint32_t x = tx; x < x1; x++) pix.push_back(y * W + x);
+    }
+    return pix;
+}
+
+int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const PassPlan& pp, EventTimer* tm) {
+    const DevScene& d = s->dev;
+    const uint32_t spp_pass = pp.s_hi - pp.s_lo;
+    const uint32_t n_paths = pp.n_pix * spp_pass;
+    hipStream_t st = c->stream;
+    Counters* ctr = c->counters;
+    const bool count = prm.count_traversal != 0;
+
+    if (tm) { int e = tm->begin(FAM_OTHER); if (e) return e; }
+    hipLaunchKernelGGL(k_raygen, dim3(grid_for(c, n_paths, 8)), dim3(kBlock), 0, st, d, c->ps, c->pix_list, pp.px0, n_paths, spp_pass, pp.s_lo, prm.seed);
+    if (tm) { int e = tm->end(); if (e) return e; }
+
+    for (uint32_t b = 0; b < d.max_depth; b++) {
+        const uint32_t* q = b == 0 ? nullptr : c->queue[b & 1];
+        const unsigned int* nq = b == 0 ? nullptr : &ctr->n_active[b & 1];
+        uint32_t* q_next = c->queue[(b + 1) & 1];
+        unsigned int* n_next = &ctr->n_active[(b + 1) & 1];
+        // an upper bound of the live paths is not known on the host: size the grids for the pass
+        const int g_trace = grid_for(c, n_paths, 8);
+        const int g_shade = grid_for(c, n_paths, 4);
+
+        if (tm) { int e = tm->begin(FAM_CLOSEST); if (e) return e; }
+        if (count) hipLaunchKernelGGL((k_trace<false, true>), dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, q, nq, n_paths, (const double*)nullptr, ctr);
+        else hipLaunchKernelGGL((k_trace<false, false>), dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, q, nq, n_paths, (const double*)nullptr, ctr);
+        if (tm) { int e = tm->end(); if (e) return e; }
+
+        HIP_TRY(hipMemsetAsync(n_next, 0, sizeof(unsigned int), st));
+        HIP_TRY(hipMemsetAsync(&ctr->n_shadow, 0, sizeof(unsigned int), st));
+        if (tm) { int e = tm->begin(FAM_SHADE); if (e) return e; }
+        hipLaunchKernelGGL(k_shade, dim3(g_shade), dim3(kBlock), 0, st, d, c->ps, q, nq, n_paths, b, spp_pass, pp.s_lo, q_next, n_next,
+                           c->shadow_queue, &ctr->n_shadow, ctr);
+        if (tm) { int e = tm->end(); if (e) return e; }
+
+        if (tm) { int e = tm->begin(FAM_ANY); if (e) return e; }
+        if (count) hipLaunchKernelGGL((k_trace<true, true>), dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, c->shadow_queue, &ctr->n_shadow, 0u, (const double*)nullptr, ctr);
+        else hipLaunchKernelGGL((k_trace<true, false>), dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, c->shadow_queue, &ctr->n_shadow, 0u, (const double*)nullptr, ctr);
+        if (tm) { int e = tm->end(); if (e) return e; }
+    }
+    if (tm) { int e = tm->begin(FAM_OTHER); if (e) return e; }
+    hipLaunchKernelGGL(k_film, dim3(grid_for(c, pp.n_pix, 8)), dim3(kBlock), 0, st, c->ps, c->pix_list, pp.px0, pp.n_pix, spp_pass, pp.s_lo,
+                       prm.sample_batch, c->film, ctr);
+    if (tm) { int e = tm->end(); if (e) return e; }
+    HIP_TRY(hipGetLastError());
+    return CRAY_OK;
+}
+
+int check_render_args(cray_ctx* c, cray_scene* s, const cray_render_params* p) {
+    if (!c || !s || !p) { set_last_error("cray_render: null argument"); return CRAY_ERR_INVALID; }
+    if (s->ctx != c) { set_last_error("scene was uploaded through a different context"); return CRAY_ERR_INVALID; }
+    if (p->tile_width == 0 || p->tile_height == 0 || p->sample_batch == 0 || p->world_size == 0 || p->rank >= p->world_size) {
+        set_last_error("cray_render: bad tile/batch/rank parameters");
+        return CRAY_ERR_INVALID;
+    }
+    if (s->dev.num_samples > 65536) { set_last_error("sobol_burley indexes at most 2^16 samples"); return CRAY_ERR_UNSUPPORTED; }
+    return CRAY_OK;
+}
+
+// plan passes: whole sample batches x pixel blocks, ascending batches outermost per pixel block
+std::vector<PassPlan> plan(size_t capacity, uint32_t n_pix, uint32_t s_begin, uint32_t s_end, uint32_t batch) {
+    std::vector<PassPlan> out;
+    if (n_pix == 0 || s_end <= s_begin) return out;
+    size_t per_batch_all = (size_t)n_pix * batch;
+    if (per_batch_all <= capacity) {
+        uint32_t k = (uint32_t)(capacity / per_batch_all);  // batches per pass
+        uint32_t s = s_begin;
+        while (s < s_end) {
+            uint32_t first_batch_end = (s / batch + 1) * batch;
+            uint32_t hi = first_batch_end + (k - 1) * batch;
+            if (hi > s_end) hi = s_end;
+            out.push_back(PassPlan{0, n_pix, s, hi});
+            s = hi;
+        }
+    } else {
+        uint32_t chunk = (uint32_t)(capacity / batch);
+        for (uint32_t px = 0; px < n_pix; px += chunk) {
+            uint32_t np = n_pix - px < chunk ? n_pix - px : chunk;
+            uint32_t s = s_begin;
+            while (s < s_end) {
+                uint32_t hi = (s / batch + 1) * batch;
+                if (hi > s_end) hi = s_end;
+                out.push_back(PassPlan{px, np, s, hi});
+                s = hi;
+            }
+        }
+    }
+    return out;
+}
+
+}  // namespace
+
+extern "C" int cray_render(cray_ctx* c, cray_scene* s, const cray_render_params* prm, float* out_rgb, cray_stats* stats) {
+    int e = check_render_args(c, s, prm);
+    if (e) return e;
+    if (!out_rgb) { set_last_error("cray_render: out_rgb is null"); return CRAY_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(c->device));
+    const DevScene& d = s->dev;
+    const uint32_t W = d.film_w, H = d.film_h;
+    uint32_t s_begin = prm->sample_begin, s_end = prm->sample_end;
+    if (s_begin == 0 && s_end == 0) s_end = d.num_samples;
+    if (s_end > d.num_samples) s_end = d.num_samples;
+
+    std::vector<uint32_t> pix = rank_pixels(W, H, *prm);
+    if (pix.size() > c->pix_capacity) {
+        if (c->pix_list) hipFree(c->pix_list);
+        c->pix_list = nullptr; c->pix_capacity = 0;
+        HIP_TRY(hipMalloc((void**)&c->pix_list, pix.size() * 4));
+        c->pix_capacity = pix.size();
+    }
+    const size_t film_floats = (size_t)W * H * 3;
+    if (film_floats > c->film_floats) {
+        if (c->film) hipFree(c->film);
+        c->film = nullptr; c->film_floats = 0;
+        HIP_TRY(hipMalloc((void**)&c->film, film_floats * sizeof(float)));
+        c->film_floats = film_floats;
+    }
+    size_t capacity = prm->max_paths_in_flight ? (size_t)prm->max_paths_in_flight : ((size_t)32 << 20);
+    size_t need = (size_t)pix.size() * (s_end > s_begin ? s_end - s_begin : 0);
+    if (need < capacity) capacity = need;
+    if (capacity < prm->sample_batch) capacity = prm->sample_batch;
+    if (capacity >= ((size_t)1 << 32)) capacity = ((size_t)1 << 32) - 1;
+    if ((e = ensure_state(c, capacity))) return e;
+    std::vector<PassPlan> passes = plan(c->capacity, (uint32_t)pix.size(), s_begin, s_end, prm->sample_batch);
+
+    if (!pix.empty()) HIP_TRY(hipMemcpyAsync(c->pix_list, pix.data(), pix.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->film, 0, film_floats * sizeof(float), c->stream));
+    HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(Counters), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+
+    EventTimer timer(c);
+    EventTimer* tm = stats ? &timer : nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    for (const PassPlan& pp : passes)
+        if ((e = run_pass(c, s, *prm, pp, tm))) return e;
+
+    float* dst = out_rgb;
+    float* staging = nullptr;
+    if (!prm->out_is_device) {
+        HIP_TRY(hipMalloc((void**)&staging, film_floats * sizeof(float)));
+        dst = staging;
+    }
+    hipLaunchKernelGGL(k_resolve, dim3(grid_for(c, film_floats, 8)), dim3(kBlock), 0, c->stream, c->film, dst, film_floats, (float)d.num_samples);
+    hipError_t err = hipStreamSynchronize(c->stream);
+    auto t1 = std::chrono::steady_clock::now();
+    if (err == hipSuccess && staging) err = hipMemcpy(out_rgb, staging, film_floats * sizeof(float), hipMemcpyDeviceToHost);
+    if (staging) hipFree(staging);
+    if (err != hipSuccess) { set_last_error("render failed: %s", hipGetErrorString(err)); return CRAY_ERR_HIP; }
+
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        Counters h;
+        HIP_TRY(hipMemcpy(&h, c->counters, sizeof(h), hipMemcpyDeviceToHost));
+        fill_stats(h, stats);
+        stats->paths = need;
+        stats->seconds = std::chrono::duration<double>(t1 - t0).count();
+        double ms[4]; uint32_t launches[4];
+        if ((e = timer.collect(ms, launches))) return e;
+        stats->trace_closest_ms = ms[FAM_CLOSEST]; stats->trace_any_ms = ms[FAM_ANY];
+        stats->shade_ms = ms[FAM_SHADE]; stats->other_ms = ms[FAM_OTHER];
+        stats->trace_closest_launches = launches[FAM_CLOSEST]; stats->trace_any_launches = launches[FAM_ANY];
+        stats->shade_launches = launches[FAM_SHADE];
+    }
+    return CRAY_OK;
+}
+
+// per-path radiance: out_L[(pixel_in_row_major * n + j)][3], n = sample_end - sample_begin (one batch at most)
+extern "C" int cray_render_samples(cray_ctx* c, cray_scene* s, const cray_render_params* prm, double* out_L) {
+    int e = check_render_args(c, s, prm);
+    if (e) return e;
+    if (!out_L) { set_last_error("cray_render_samples: out_L is null"); return CRAY_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(c->device));
+    const DevScene& d = s->dev;
+    uint32_t s_begin = prm->sample_begin, s_end = prm->sample_end;
+    if (s_begin == 0 && s_end == 0) s_end = d.num_samples;
+    if (s_end > d.num_samples || s_end <= s_begin || prm->world_size != 1) { set_last_error("cray_render_samples: bad sample range / needs world_size 1"); return CRAY_ERR_INVALID; }
+    const uint32_t n = s_end - s_begin;
+    const size_t n_pix = (size_t)d.film_w * d.film_h;
+    if (n_pix * n >= ((size_t)1 << 32)) { set_last_error("cray_render_samples: too many paths"); return CRAY_ERR_UNSUPPORTED; }
+    std::vector<uint32_t> pix(n_pix);
+    for (size_t i = 0; i < n_pix; i++) pix[i] = (uint32_t)i;
+    if (pix.size() > c->pix_capacity) {
+        if (c->pix_list) hipFree(c->pix_list);
+        c->pix_list = nullptr; c->pix_capacity = 0;
+        HIP_TRY(hipMalloc((void**)&c->pix_list, pix.size() * 4));
+        c->pix_capacity = pix.size();
+    }
+    const size_t film_floats = n_pix * 3;
+    if (film_floats > c->film_floats) {
+        if (c->film) hipFree(c->film);
+        c->film = nullptr; c->film_floats = 0;
+        HIP_TRY(hipMalloc((void**)&c->film, film_floats * sizeof(float)));
+        c->film_floats = film_floats;
+    }
+    if ((e = ensure_state(c, n_pix * n))) return e;
+    HIP_TRY(hipMemcpyAsync(c->pix_list, pix.data(), pix.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->film, 0, film_floats * sizeof(float), c->stream));
+    HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(Counters), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    cray_render_params p2 = *prm;
+    p2.sample_batch = n > p2.sample_batch ? n : p2.sample_batch;
+    PassPlan pp{0, (uint32_t)n_pix, s_begin, s_end};
+    if ((e = run_pass(c, s, p2, pp, nullptr))) return e;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<double> r(n_pix * n), g(n_pix * n), b(n_pix * n);
+    HIP_TRY(hipMemcpy(r.data(), c->ps.lr, r.size() * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(g.data(), c->ps.lg, g.size() * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(b.data(), c->ps.lb, b.size() * 8, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < r.size(); i++) { out_L[3 * i] = r[i]; out_L[3 * i + 1] = g[i]; out_L[3 * i + 2] = b[i]; }
+    return CRAY_OK;
+}
+
+extern "C" int cray_trace(cray_ctx* c, cray_scene* s, const cray_ray* rays, size_t n, cray_hit* hits, int any_hit, cray_stats* stats) {
+    if (!c || !s || (!rays && n) || (!hits && n)) { set_last_error("cray_trace: null argument"); return CRAY_ERR_INVALID; }
+    if (s->ctx != c) { set_last_error("scene was uploaded through a different context"); return CRAY_ERR_INVALID; }
+    if (n >= ((size_t)1 << 31)) { set_last_error("cray_trace: too many rays in one call"); return CRAY_ERR_UNSUPPORTED; }
+    HIP_TRY(hipSetDevice(c->device));
+    if (n == 0) { if (stats) memset(stats, 0, sizeof(*stats)); return CRAY_OK; }
+    int e;
+    if ((e = ensure_state(c, n))) return e;
+    std::vector<double> col(n);
+    PathState& ps = c->ps;
+    double* dst_o[3] = {any_hit ? ps.sox : ps.ox, any_hit ? ps.soy : ps.oy, any_hit ? ps.soz : ps.oz};
+    double* dst_d[3] = {any_hit ? ps.sdx : ps.dx, any_hit ? ps.sdy : ps.dy, any_hit ? ps.sdz : ps.dz};
+    for (int k = 0; k < 3; k++) {
+        for (size_t i = 0; i < n; i++) col[i] = rays[i].o[k];
+        HIP_TRY(hipMemcpy(dst_o[k], col.data(), n * 8, hipMemcpyHostToDevice));
+        for (size_t i = 0; i < n; i++) col[i] = rays[i].d[k];
+        HIP_TRY(hipMemcpy(dst_d[k], col.data(), n * 8, hipMemcpyHostToDevice));
+    }
+    for (size_t i = 0; i < n; i++) col[i] = rays[i].tmax;
+    HIP_TRY(hipMemcpy(ps.stmax, col.data(), n * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(Counters), c->stream));
+    // any-hit resolution adds `contribution` to L: use L as the "unoccluded" flag (0 + 1)
+    if (any_hit) {
+        for (size_t i = 0; i < n; i++) col[i] = 0.0;
+        HIP_TRY(hipMemcpy(ps.lr, col.data(), n * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ps.lg, col.data(), n * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ps.lb, col.data(), n * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ps.cg, col.data(), n * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ps.cb, col.data(), n * 8, hipMemcpyHostToDevice));
+        for (size_t i = 0; i < n; i++) col[i] = 1.0;
+        HIP_TRY(hipMemcpy(ps.cr, col.data(), n * 8, hipMemcpyHostToDevice));
+    }
+    const int g = grid_for(c, n, 8);
+    if (any_hit) {
+        hipLaunchKernelGGL((k_trace<true, true>), dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)nullptr, (const unsigned int*)nullptr, (uint32_t)n, (const double*)nullptr, c->counters);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpy(col.data(), ps.lr, n * 8, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; i++) {
+            memset(&hits[i], 0, sizeof(cray_hit));
+            hits[i].hit = col[i] == 0.0 ? 1 : 0;
+            hits[i].prim = -1;
+        }
+    } else {
+        // closest hit with caller-supplied tmax: rays whose tmax is finite go through the same kernel via stmax
+        hipLaunchKernelGGL((k_trace<false, true>), dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)nullptr, (const unsigned int*)nullptr, (uint32_t)n, (const double*)ps.stmax, c->counters);
+        cray_hit* d_hits = nullptr;
+        HIP_TRY(hipMalloc((void**)&d_hits, n * sizeof(cray_hit)));
+        hipLaunchKernelGGL(k_hit_records, dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (uint32_t)n, d_hits);
+        hipError_t err = hipStreamSynchronize(c->stream);
+        if (err == hipSuccess) err = hipMemcpy(hits, d_hits, n * sizeof(cray_hit), hipMemcpyDeviceToHost);
+        hipFree(d_hits);
+        if (err != hipSuccess) { set_last_error("cray_trace failed: %s", hipGetErrorString(err)); return CRAY_ERR_HIP; }
+    }
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        Counters h;
+        HIP_TRY(hipMemcpy(&h, c->counters, sizeof(h), hipMemcpyDeviceToHost));
+        fill_stats(h, stats);
+    }
+    return CRAY_OK;
+}

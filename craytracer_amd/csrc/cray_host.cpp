@@ -1,0 +1,502 @@
+// cray_host.cpp — host-side mirror of craytracer's `Scene::new` (include/cray_host.h).
+//
+// Builds, on the CPU and untimed by the render metric:
+//   * Sphere/Disk transformation pairs and all primitive bounds   (src/shape.rs:55-69,133-153,402-438)
+//   * the reference-topology BVH, so that traversal order, leaf order and equal-t
+//     tie-breaks on the GPU are those of the reference              (src/bvh.rs:38-56,191-336)
+//   * camera matrices                                               (src/camera.rs:25-76)
+//   * the power-proportional light CDF                              (src/light.rs:170-200)
+//   * first-equal light indices                                     (src/path_integrator.rs:116)
+// and exposes them as a cray_flat_scene for cray_scene_upload.
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/cray_host.h"
+#include "cray_math.h"
+
+namespace cray {
+void set_last_error(const char* fmt, ...);  // cray_hip.hip
+}
+
+namespace {
+using namespace cray;
+
+// ---------------------------------------------------------------- matrices
+mat4 identity() {
+    mat4 r;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) r.m[i][j] = i == j ? 1.0 : 0.0;
+    return r;
+}
+mat4 mul(const mat4& a, const mat4& b) {  // transformation.rs:202-218: acc starts at 0.0, k ascending
+    mat4 r;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            double acc = 0.0;
+            for (int k = 0; k < 4; k++) acc += a.m[i][k] * b.m[k][j];
+            r.m[i][j] = acc;
+        }
+    return r;
+}
+mat4 transpose(const mat4& a) {
+    mat4 r;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) r.m[i][j] = a.m[j][i];
+    return r;
+}
+// Matrix::inverse (transformation.rs:71-195): adjugate over determinant.  Entry (i,j) is the
+// signed 3x3 minor with row j and column i removed, expanded along the first remaining column,
+// each product evaluated left to right and the six products summed in expansion order —
+// which is the order the reference writes them in.
+bool inverse(const mat4& a, mat4& out) {
+    double adj[4][4];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            int R[3], K[3], nr = 0, nk = 0;
+            for (int t = 0; t < 4; t++) {
+                if (t != j) R[nr++] = t;
+                if (t != i) K[nk++] = t;
+            }
+            double sgn = ((i + j) & 1) ? -1.0 : 1.0;
+            double acc = 0.0;
+            bool first = true;
+            for (int p = 0; p < 3; p++) {
+                int r = R[p], ra = R[p == 0 ? 1 : 0], rb = R[p == 2 ? 1 : 2];
+                double s = (p & 1) ? -sgn : sgn;
+                double head_pos = a.m[r][K[0]], head_neg = -a.m[r][K[0]];
+                // + head * m[ra][K1] * m[rb][K2]
+                double t1 = (s > 0 ? head_pos : head_neg) * a.m[ra][K[1]] * a.m[rb][K[2]];
+                // - head * m[ra][K2] * m[rb][K1]
+                double t2 = (s > 0 ? head_pos : head_neg) * a.m[ra][K[2]] * a.m[rb][K[1]];
+                if (first) { acc = t1; first = false; } else acc = acc + t1;
+                acc = acc - t2;
+            }
+            adj[i][j] = acc;
+        }
+    double det = a.m[0][0] * adj[0][0] + a.m[0][1] * adj[1][0] + a.m[0][2] * adj[2][0] + a.m[0][3] * adj[3][0];
+    if (det == 0.0) return false;
+    double inv_det = 1.0 / det;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) out.m[i][j] = adj[i][j] * inv_det;
+    return true;
+}
+
+xform compose(const xform& a, const xform& b) { return xform{mul(a.fwd, b.fwd), mul(b.inv, a.inv)}; }  // :392-412
+xform swapped(const xform& t) { return xform{t.inv, t.fwd}; }                                           // :262-267
+xform translate(double dx, double dy, double dz) {                                                      // :269-288
+    xform t{identity(), identity()};
+    t.fwd.m[0][3] = dx; t.fwd.m[1][3] = dy; t.fwd.m[2][3] = dz;
+    t.inv.m[0][3] = -dx; t.inv.m[1][3] = -dy; t.inv.m[2][3] = -dz;
+    return t;
+}
+xform scale(double x, double y, double z) {                                                             // :290-309
+    xform t{identity(), identity()};
+    t.fwd.m[0][0] = x; t.fwd.m[1][1] = y; t.fwd.m[2][2] = z;
+    t.inv.m[0][0] = 1.0 / x; t.inv.m[1][1] = 1.0 / y; t.inv.m[2][2] = 1.0 / z;
+    return t;
+}
+xform rotate_x(double rad) {                                                                             // :311-324
+    double s = sin(rad), c = cos(rad);
+    xform t; t.fwd = identity();
+    t.fwd.m[1][1] = c; t.fwd.m[1][2] = -s; t.fwd.m[2][1] = s; t.fwd.m[2][2] = c;
+    t.inv = transpose(t.fwd);
+    return t;
+}
+xform rotate_y(double rad) {                                                                             // :326-339
+    double s = sin(rad), c = cos(rad);
+    xform t; t.fwd = identity();
+    t.fwd.m[0][0] = c; t.fwd.m[0][2] = s; t.fwd.m[2][0] = -s; t.fwd.m[2][2] = c;
+    t.inv = transpose(t.fwd);
+    return t;
+}
+bool look_at(vec3 origin, vec3 target, vec3 up, xform& t) {                                              // :356-370
+    vec3 z = unit(target - origin);
+    vec3 x = unit(cross(unit(up), z));
+    vec3 y = unit(cross(z, x));
+    double rows[4][4] = {{x.x, y.x, z.x, origin.x}, {x.y, y.y, z.y, origin.y}, {x.z, y.z, z.z, origin.z}, {0, 0, 0, 1}};
+    memcpy(t.fwd.m, rows, sizeof(rows));
+    return inverse(t.fwd, t.inv);
+}
+bool perspective(double fov, double near, double far, xform& out) {                                      // :372-385
+    xform p;
+    double rows[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, far / (far - near), -far * near / (far - near)}, {0, 0, 1, 0}};
+    memcpy(p.fwd.m, rows, sizeof(rows));
+    if (!inverse(p.fwd, p.inv)) return false;
+    double inv_tan = 1.0 / tan(deg2rad(fov) * 0.5);
+    out = compose(p, scale(inv_tan, inv_tan, 1.0));
+    return true;
+}
+xform orthographic(double near, double far) {                                                            // :387-389
+    return compose(scale(1.0, 1.0, 1.0 / (far - near)), translate(0.0, 0.0, -near));
+}
+
+// ---------------------------------------------------------------- bounds
+struct box3 {
+    vec3 lo, hi;
+};
+box3 box_of(vec3 a, vec3 b) {  // Bounds::new
+    return box3{mk(min_nn(a.x, b.x), min_nn(a.y, b.y), min_nn(a.z, b.z)), mk(max_nn(a.x, b.x), max_nn(a.y, b.y), max_nn(a.z, b.z))};
+}
+box3 join(const box3& a, const box3& b) {  // Add for Bounds
+    return box3{mk(min_nn(a.lo.x, b.lo.x), min_nn(a.lo.y, b.lo.y), min_nn(a.lo.z, b.lo.z)),
+                mk(max_nn(a.hi.x, b.hi.x), max_nn(a.hi.y, b.hi.y), max_nn(a.hi.z, b.hi.z))};
+}
+double area(const box3& b) {  // surface_area, bounds.rs:29-32
+    vec3 d = b.hi - b.lo;
+    return 2.0 * (d.x * d.y + d.y * d.z + d.z * d.x);
+}
+int widest(const box3& b) {  // maximum_extent, bounds.rs:36-45
+    vec3 d = b.hi - b.lo;
+    if (d.x > d.y && d.x > d.z) return 0;
+    return d.y > d.z ? 1 : 2;
+}
+box3 xf_box(const mat4& m, const box3& b) {  // Transformable<Bounds>, transformation.rs:465-481
+    const double* mm = &m.m[0][0];
+    box3 acc{};
+    int n = 0;
+    for (int ix = 0; ix < 2; ix++)
+        for (int iy = 0; iy < 2; iy++)
+            for (int iz = 0; iz < 2; iz++) {
+                vec3 p = xf_point(mm, mk(ix ? b.hi.x : b.lo.x, iy ? b.hi.y : b.lo.y, iz ? b.hi.z : b.lo.z));
+                acc = n++ == 0 ? box_of(p, p) : join(acc, box_of(p, p));
+            }
+    return acc;
+}
+
+// ---------------------------------------------------------------- BVH build
+struct Item {
+    uint32_t prim;
+    box3 box;
+    vec3 centroid;
+};
+
+struct Builder {
+    std::vector<cray_bvh_node> nodes;
+    std::vector<uint32_t> refs;
+    int error = 0;
+
+    uint32_t leaf(const Item* it, size_t n, const box3& b) {
+        cray_bvh_node nd;
+        memset(&nd, 0, sizeof(nd));
+        nd.bmin[0] = b.lo.x; nd.bmin[1] = b.lo.y; nd.bmin[2] = b.lo.z;
+        nd.bmax[0] = b.hi.x; nd.bmax[1] = b.hi.y; nd.bmax[2] = b.hi.z;
+        nd.first = (uint32_t)refs.size();
+        nd.count = (uint32_t)n;
+        nd.is_leaf = 1;
+        for (size_t i = 0; i < n; i++) refs.push_back(it[i].prim);
+        nodes.push_back(nd);
+        return (uint32_t)nodes.size() - 1;
+    }
+    uint32_t interior(const box3& b, int axis) {
+        cray_bvh_node nd;
+        memset(&nd, 0, sizeof(nd));
+        nd.bmin[0] = b.lo.x; nd.bmin[1] = b.lo.y; nd.bmin[2] = b.lo.z;
+        nd.bmax[0] = b.hi.x; nd.bmax[1] = b.hi.y; nd.bmax[2] = b.hi.z;
+        nd.axis = axis;
+        nodes.push_back(nd);
+        return (uint32_t)nodes.size() - 1;
+    }
+
+    // BvhNode::from_sah_splitting (bvh.rs:234-336)
+    uint32_t sah(Item* it, size_t n) {
+        constexpr int kBuckets = 12;
+        constexpr double kTraversalCost = 1.0 / 8.0;
+        constexpr size_t kMaxLeaf = 4;
+        box3 all = it[0].box;
+        for (size_t i = 1; i < n; i++) all = join(all, it[i].box);
+        if (n <= 1) return leaf(it, n, all);
+        double total_area = area(all);
+        if (!(total_area > 0.0)) { error = 1; return leaf(it, n, all); }  // assert!, bvh.rs:245
+
+        box3 cb = box_of(it[0].centroid, it[0].centroid);
+        for (size_t i = 1; i < n; i++) cb = join(cb, box_of(it[i].centroid, it[i].centroid));
+        const int axis = widest(cb);
+        const double c_lo = comp(cb.lo, axis), c_hi = comp(cb.hi, axis);
+        auto bucket_of = [&](const Item& p) -> int {
+            double off = (comp(p.centroid, axis) - c_lo) / (c_hi - c_lo);  // Bounds::offset, bounds.rs:55-61
+            uint64_t idx = to_u64_sat((double)kBuckets * off);
+            return (int)(idx < (uint64_t)(kBuckets - 1) ? idx : (uint64_t)(kBuckets - 1));
+        };
+        bool used[kBuckets] = {};
+        box3 bbox[kBuckets];
+        size_t bcnt[kBuckets] = {};
+        for (size_t i = 0; i < n; i++) {
+            int b = bucket_of(it[i]);
+            if (used[b]) { bbox[b] = join(bbox[b], it[i].box); bcnt[b]++; }
+            else { used[b] = true; bbox[b] = it[i].box; bcnt[b] = 1; }
+        }
+        double cost[kBuckets - 1];
+        for (int s = 0; s < kBuckets - 1; s++) {
+            double c = kTraversalCost;
+            for (int side = 0; side < 2; side++) {
+                int b0 = side ? s + 1 : 0, b1 = side ? kBuckets : s + 1;
+                bool any = false;
+                box3 mb{};
+                size_t mc = 0;
+                for (int b = b0; b < b1; b++) {
+                    if (!used[b]) continue;
+                    if (any) { mb = join(mb, bbox[b]); mc += bcnt[b]; }
+                    else { any = true; mb = bbox[b]; mc = bcnt[b]; }
+                }
+                if (any) c += (double)mc * area(mb) / total_area;
+            }
+            if (!isfinite(c)) error = 2;  // assert!(cost.is_finite()), bvh.rs:304
+            cost[s] = c;
+        }
+        int best = 0;
+        for (int s = 0; s < kBuckets - 1; s++)
+            if (cost[s] < cost[best]) best = s;
+        if ((double)n <= cost[best] && n <= kMaxLeaf) return leaf(it, n, all);
+
+        // util::partition_by (util.rs:4-26) with pred = bucket <= best
+        size_t l = 0, r = n - 1;
+        auto pred = [&](const Item& p) { return bucket_of(p) <= best; };
+        while (l != r) {
+            while (l < r && pred(it[l])) l++;
+            while (r > l && !pred(it[r])) r--;
+            std::swap(it[l], it[r]);
+        }
+        size_t split = pred(it[l]) ? l + 1 : l;
+        if (split == 0 || split == n) { error = 3; return leaf(it, n, all); }  // assert!, bvh.rs:327-328
+
+        uint32_t me = interior(all, axis);
+        uint32_t a = sah(it, split);
+        uint32_t b = sah(it + split, n - split);
+        nodes[me].left = a;
+        nodes[me].right = b;
+        return me;
+    }
+
+    // BvhNode::from_median_splitting (bvh.rs:191-230). Only the n <= 4 -> single leaf case is
+    // pinned by the reference tests; the selection permutation of select_nth_unstable_by is
+    // implementation-defined, std::nth_element is used for larger inputs.
+    uint32_t median(Item* it, size_t n) {
+        box3 all = it[0].box;
+        for (size_t i = 1; i < n; i++) all = join(all, it[i].box);
+        if (n <= 4) return leaf(it, n, all);
+        box3 cb = box_of(it[0].centroid, it[0].centroid);
+        for (size_t i = 1; i < n; i++) cb = join(cb, box_of(it[i].centroid, it[i].centroid));
+        int axis = widest(cb);
+        if (comp(cb.lo, axis) == comp(cb.hi, axis)) return leaf(it, n, all);
+        size_t mid = (n - 1) / 2;
+        std::nth_element(it, it + mid, it + n, [&](const Item& a, const Item& b) { return comp(a.centroid, axis) < comp(b.centroid, axis); });
+        if (mid == 0) mid = 1;
+        uint32_t me = interior(all, axis);
+        uint32_t a = median(it, mid);
+        uint32_t b = median(it + mid, n - mid);
+        nodes[me].left = a;
+        nodes[me].right = b;
+        return me;
+    }
+};
+
+void store16(const mat4& m, double* out) { memcpy(out, m.m, sizeof(double) * 16); }
+
+}  // namespace
+
+struct cray_host_scene {
+    cray_flat_scene flat;
+    std::vector<cray_bvh_node> nodes;
+    std::vector<uint32_t> refs;
+    std::vector<cray_xf_shape> spheres, disks;
+    std::vector<double> cdf;
+    std::vector<int32_t> first_equal;
+    double build_seconds;
+};
+
+extern "C" int cray_host_scene_new(const cray_scene_desc* d, int split_method, cray_host_scene** out) {
+    using namespace cray;
+    if (!d || !out) { set_last_error("cray_host_scene_new: null argument"); return CRAY_ERR_INVALID; }
+    *out = nullptr;
+    if (d->n_lights == 0) { set_last_error("No lights in the scene."); return CRAY_ERR_INVALID; }
+    if (d->n_prims == 0) { set_last_error("Bvh::new: no primitives"); return CRAY_ERR_BUILD; }
+    auto t0 = std::chrono::steady_clock::now();
+    cray_host_scene* hs = new cray_host_scene();
+
+    // --- Sphere / Disk transformation pairs (shape.rs:55-69, 133-153)
+    hs->spheres.resize(d->n_spheres);
+    for (uint32_t i = 0; i < d->n_spheres; i++) {
+        const cray_sphere_desc& s = d->spheres[i];
+        xform t = translate(s.origin.x, s.origin.y, s.origin.z);
+        store16(t.fwd, hs->spheres[i].m);
+        store16(t.inv, hs->spheres[i].inv);
+        hs->spheres[i].radius = s.radius;
+        hs->spheres[i].inner_radius = 0.0;
+    }
+    hs->disks.resize(d->n_disks);
+    for (uint32_t i = 0; i < d->n_disks; i++) {
+        const cray_disk_desc& s = d->disks[i];
+        xform t = compose(compose(translate(s.origin.x, s.origin.y, s.origin.z), rotate_x(deg2rad(s.rotate_x))),
+                          rotate_y(deg2rad(s.rotate_y)));
+        store16(t.fwd, hs->disks[i].m);
+        store16(t.inv, hs->disks[i].inv);
+        hs->disks[i].radius = s.radius;
+        hs->disks[i].inner_radius = s.inner_radius;
+    }
+
+    // --- primitive bounds (shape.rs:402-438) and Bvh::new (bvh.rs:38-56)
+    std::vector<Item> items(d->n_prims);
+    for (uint32_t i = 0; i < d->n_prims; i++) {
+        const cray_prim& p = d->prims[i];
+        box3 b;
+        bool ok = true;
+        if (p.shape_kind == CRAY_SHAPE_TRIANGLE) {
+            ok = p.shape < d->n_triangles;
+            if (ok) {
+                const cray_triangle& t = d->triangles[p.shape];
+                vec3 v0 = mk(t.v0.x, t.v0.y, t.v0.z);
+                vec3 v1 = v0 + mk(t.e1.x, t.e1.y, t.e1.z), v2 = v0 + mk(t.e2.x, t.e2.y, t.e2.z);
+                b = box_of(mk(min_nn(v1.x, min_nn(v2.x, v0.x)), min_nn(v1.y, min_nn(v2.y, v0.y)), min_nn(v1.z, min_nn(v2.z, v0.z))),
+                           mk(max_nn(v1.x, max_nn(v2.x, v0.x)), max_nn(v1.y, max_nn(v2.y, v0.y)), max_nn(v1.z, max_nn(v2.z, v0.z))));
+            }
+        } else if (p.shape_kind == CRAY_SHAPE_SPHERE) {
+            ok = p.shape < d->n_spheres;
+            if (ok) {
+                double r = hs->spheres[p.shape].radius;
+                mat4 m; memcpy(m.m, hs->spheres[p.shape].m, sizeof(m.m));
+                b = xf_box(m, box_of(mk(-r, -r, -r), mk(r, r, r)));
+            }
+        } else if (p.shape_kind == CRAY_SHAPE_DISK) {
+            ok = p.shape < d->n_disks;
+            if (ok) {
+                double r = hs->disks[p.shape].radius;
+                mat4 m; memcpy(m.m, hs->disks[p.shape].m, sizeof(m.m));
+                b = xf_box(m, box_of(mk(-r, -r, 0.0), mk(r, r, 0.0)));
+            }
+        } else ok = false;
+        if (!ok || (p.material >= (int32_t)d->n_materials) || (p.light >= (int32_t)d->n_lights) ||
+            (p.material < 0 && p.light < 0)) {
+            set_last_error("cray_host_scene_new: primitive %u has a bad shape/material/light index", i);
+            delete hs;
+            return CRAY_ERR_INVALID;
+        }
+        items[i].prim = i;
+        items[i].box = b;
+        items[i].centroid = mk((b.lo.x + b.hi.x) * 0.5, (b.lo.y + b.hi.y) * 0.5, (b.lo.z + b.hi.z) * 0.5);
+    }
+    Builder bld;
+    bld.nodes.reserve((size_t)d->n_prims * 2);
+    bld.refs.reserve(d->n_prims);
+    if (split_method == CRAY_SPLIT_MEDIAN) bld.median(items.data(), items.size());
+    else bld.sah(items.data(), items.size());
+    if (bld.error) {
+        set_last_error("Bvh::new would panic in the reference (code %d: 1 zero surface area, 2 non-finite cost, 3 empty partition)", bld.error);
+        delete hs;
+        return CRAY_ERR_BUILD;
+    }
+    box3 world = items[0].box;
+    for (size_t i = 1; i < items.size(); i++) world = join(world, items[i].box);
+    hs->nodes.swap(bld.nodes);
+    hs->refs.swap(bld.refs);
+
+    // --- LightSampler::new (light.rs:187-200) with Light::power (:170-177), world_radius (scene.rs:42)
+    double world_radius = len(world.hi - world.lo) * 0.5;
+    hs->cdf.resize(d->n_lights);
+    double total_power = 0.0;
+    for (uint32_t i = 0; i < d->n_lights; i++) {
+        const cray_light& l = d->lights[i];
+        rgb c = mkc(l.c.r, l.c.g, l.c.b), power;
+        if (l.kind == CRAY_LIGHT_POINT) power = c * 4.0 * kPi;
+        else if (l.kind == CRAY_LIGHT_DISTANT || l.kind == CRAY_LIGHT_INFINITE) power = c * kPi * world_radius * world_radius;
+        else {
+            if (l.prim < 0 || (uint32_t)l.prim >= d->n_prims) { set_last_error("area light %u: bad prim index", i); delete hs; return CRAY_ERR_INVALID; }
+            const cray_prim& p = d->prims[l.prim];
+            double a;  // Shape::area (shape.rs:504-514); sphere is PI r^2 as in the reference
+            if (p.shape_kind == CRAY_SHAPE_SPHERE) a = kPi * square(hs->spheres[p.shape].radius);
+            else if (p.shape_kind == CRAY_SHAPE_DISK) a = kPi * (square(hs->disks[p.shape].radius) - square(hs->disks[p.shape].inner_radius));
+            else {
+                const cray_triangle& t = d->triangles[p.shape];
+                a = len(cross(mk(t.e1.x, t.e1.y, t.e1.z), mk(t.e2.x, t.e2.y, t.e2.z))) / 2.0;
+            }
+            power = c * kPi * a;
+        }
+        double avg = (power.r + power.g + power.b) / 3.0;
+        total_power += avg;
+        hs->cdf[i] = total_power;
+    }
+    for (auto& v : hs->cdf) v = v / total_power;
+
+    // --- lights.iter().position(|l| l == light) (path_integrator.rs:116): first light equal by value
+    hs->first_equal.resize(d->n_lights);
+    {
+        std::unordered_map<std::string, int32_t> seen;
+        seen.reserve(d->n_lights * 2);
+        std::vector<double> key;
+        for (uint32_t i = 0; i < d->n_lights; i++) {
+            const cray_light& l = d->lights[i];
+            key.clear();
+            key.push_back((double)l.kind);
+            key.push_back(l.c.r); key.push_back(l.c.g); key.push_back(l.c.b);
+            if (l.kind == CRAY_LIGHT_POINT || l.kind == CRAY_LIGHT_DISTANT) { key.push_back(l.v.x); key.push_back(l.v.y); key.push_back(l.v.z); }
+            else if (l.kind == CRAY_LIGHT_AREA) {
+                const cray_prim& p = d->prims[l.prim];
+                key.push_back((double)p.shape_kind);
+                if (p.shape_kind == CRAY_SHAPE_TRIANGLE) {
+                    const double* t = (const double*)&d->triangles[p.shape];
+                    key.insert(key.end(), t, t + 24);
+                } else {
+                    const cray_xf_shape& s = p.shape_kind == CRAY_SHAPE_SPHERE ? hs->spheres[p.shape] : hs->disks[p.shape];
+                    key.push_back(s.radius); key.push_back(s.inner_radius);
+                    key.insert(key.end(), s.m, s.m + 16);
+                    key.insert(key.end(), s.inv, s.inv + 16);
+                }
+            }
+            for (auto& x : key) if (x == 0.0) x = 0.0;  // -0.0 == +0.0 under PartialEq
+            std::string sk((const char*)key.data(), key.size() * sizeof(double));
+            auto f = seen.find(sk);
+            if (f == seen.end()) { seen.emplace(std::move(sk), (int32_t)i); hs->first_equal[i] = (int32_t)i; }
+            else hs->first_equal[i] = f->second;
+        }
+    }
+
+    // --- Camera::new (camera.rs:56-76) + get_camera_from_raster_transformation (:25-53)
+    cray_flat_scene& f = hs->flat;
+    memset(&f, 0, sizeof(f));
+    {
+        const cray_camera_desc& c = d->camera;
+        xform screen_from_camera, world_from_camera;
+        bool ok = true;
+        if (c.type == CRAY_CAMERA_PERSPECTIVE) ok = perspective(c.fov, 1e-2, 1000.0, screen_from_camera);  // :87-92
+        else screen_from_camera = orthographic(0.0, 1.0);                                                 // :114-117
+        ok = ok && look_at(mk(c.origin.x, c.origin.y, c.origin.z), mk(c.target.x, c.target.y, c.target.z), mk(c.up.x, c.up.y, c.up.z), world_from_camera);
+        if (!ok) { set_last_error("camera matrix is singular (reference: unwrap on None)"); delete hs; return CRAY_ERR_BUILD; }
+        double fw = (double)c.film_width;
+        double fh = (double)c.film_width;  // sic: camera.rs:30 uses film.width for the height
+        double sw, sh;
+        if (fw > fh) { sw = fw / fh; sh = 1.0; } else { sw = 1.0; sh = fh / fw; }
+        xform screen_from_raster = compose(scale(2.0 * sw / fw, -2.0 * sh / fh, 1.0), translate(-fw / 2.0, -fh / 2.0, 0.0));
+        xform camera_from_raster = compose(swapped(screen_from_camera), screen_from_raster);
+        store16(camera_from_raster.fwd, f.camera_from_raster);
+        store16(world_from_camera.fwd, f.world_from_camera);
+        f.camera_type = c.type;
+        f.film_width = c.film_width; f.film_height = c.film_height;
+        f.lens_radius = c.lens_radius; f.focal_distance = c.focal_distance;
+    }
+    f.abi_version = CRAY_ABI_VERSION;
+    f.max_depth = d->max_depth; f.num_samples = d->num_samples;
+    f.n_nodes = (uint32_t)hs->nodes.size(); f.nodes = hs->nodes.data();
+    f.n_prim_refs = (uint32_t)hs->refs.size(); f.prim_refs = hs->refs.data();
+    f.n_prims = d->n_prims; f.prims = d->prims;
+    f.n_triangles = d->n_triangles; f.triangles = d->triangles;
+    f.n_spheres = d->n_spheres; f.spheres = hs->spheres.data();
+    f.n_disks = d->n_disks; f.disks = hs->disks.data();
+    f.n_materials = d->n_materials; f.materials = d->materials;
+    f.n_bxdfs = d->n_bxdfs; f.bxdfs = d->bxdfs;
+    f.n_textures = d->n_textures; f.textures = d->textures;
+    f.n_images = d->n_images; f.images = d->images;
+    f.image_pool_bytes = d->image_pool_bytes; f.image_pool = d->image_pool;
+    f.n_lights = d->n_lights; f.lights = d->lights;
+    f.light_cdf = hs->cdf.data();
+    f.first_equal_light = hs->first_equal.data();
+    hs->build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    *out = hs;
+    return CRAY_OK;
+}
+
+extern "C" const cray_flat_scene* cray_host_scene_flat(const cray_host_scene* s) { return s ? &s->flat : nullptr; }
+extern "C" double cray_host_scene_build_seconds(const cray_host_scene* s) { return s ? s->build_seconds : 0.0; }
+extern "C" void cray_host_scene_free(cray_host_scene* s) { delete s; }

@@ -1,0 +1,428 @@
+// cray_kernels.h — the gfx950 kernels of the wavefront path tracer.
+//
+//   k_raygen        craytracer.rs:148-156 (render_pixel: start_pixel, film+lens samples, Camera::sample)
+//   k_trace<ANY>    bvh.rs:58-104 (closest) / :106-147 (any hit) + bounds.rs:46-88 + shape.rs:157-400
+//   k_shade         path_integrator.rs:54-212 minus the two BVH queries
+//   k_film          craytracer.rs:175-188 (f64 batch sum -> f32 add), k_resolve :253-259
+//
+// One loop iteration of estimate_Li is split at its two BVH queries:
+//   trace_closest -> shade (emission, NEE set-up, BSDF sample, roulette) -> trace_any (adds the
+//   NEE term if unoccluded) -> next bounce.
+// The additions to L therefore happen in the reference's order, and every path's result is
+// independent of scheduling (outputs go to per-path slots, queues only carry indices).
+#pragma once
+
+#include "cray_shading.h"
+
+namespace cray {
+
+constexpr int kBlock = 256;
+
+// ---------------------------------------------------------------------------------
+// Slab test of one child box, split into its ray.tmax-independent part.
+// Bounds::intersects (bounds.rs:62-88) returns
+//     ok && (in(tmin) || in(tmax)),  in(t) = t > EPS && t < ray.tmax
+// where ok = no early-out fired.  tmin/tmax/ok do not depend on ray.tmax, so a child is
+// summarised by one key:  accepted  <=>  key < ray.tmax
+//     key = -inf                      if Bounds::contains(origin)        (bvh.rs:70)
+//         = +inf                      if an early-out fired
+//         = min(tmin if > EPS else +inf, tmax if > EPS else +inf)        otherwise.
+// The far child is re-checked against the *shrunken* ray.tmax when it is popped, exactly
+// when the reference tests it.  The sequential early-outs equal one final test because
+// tmax only decreases and tmin only increases over the three axes.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ double child_key(const double* __restrict__ lo, const double* __restrict__ hi, vec3 o, vec3 d) {
+    double tmin = -inf64(), tmax = inf64();
+#pragma unroll
+    for (int ax = 0; ax < 3; ax++) {
+        double d_i = ax == 0 ? d.x : (ax == 1 ? d.y : d.z);
+        double o_i = ax == 0 ? o.x : (ax == 1 ? o.y : o.z);
+        double mn = lo[ax], mx = hi[ax];
+        if (sign_neg(d_i)) { double t = mn; mn = mx; mx = t; }
+        tmax = min_nn(tmax, (mx - o_i) / d_i);
+        tmin = max_nn(tmin, (mn - o_i) / d_i);
+    }
+    bool ok = !(tmax < kEps) && !(tmin > tmax);
+    bool inside = lo[0] <= o.x && lo[1] <= o.y && lo[2] <= o.z && hi[0] >= o.x && hi[1] >= o.y && hi[2] >= o.z;
+    double a = tmin > kEps ? tmin : inf64();
+    double b = tmax > kEps ? tmax : inf64();
+    double key = ok ? min_nn(a, b) : inf64();
+    return inside ? -inf64() : key;
+}
+
+struct TraceResult {
+    double t, u, v;
+    int32_t prim;
+    bool occluded;
+};
+
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ TraceResult traverse(const DevScene& sc, ray_t ray, unsigned long long& n_nodes, unsigned long long& n_prims,
+                                                unsigned long long& n_tri, unsigned int& overflow) {
+    TraceResult res;
+    res.t = 0.0; res.u = 0.0; res.v = 0.0; res.prim = -1; res.occluded = false;
+
+    uint32_t sref[kStackDepth];
+    double skey[kStackDepth];
+    int sp = 0;
+
+    if (COUNT) n_nodes += 1;
+    if (!(child_key(sc.root_lo, sc.root_hi, ray.o, ray.d) < ray.tmax)) return res;
+    uint32_t cur = sc.root_ref;
+
+    for (;;) {
+        if (ref_is_leaf(cur)) {
+            const uint32_t first = ref_leaf_first(cur), count = ref_leaf_count(cur);
+            for (uint32_t k = 0; k < count; k++) {
+                const LeafSlot& s = sc.slots[first + k];
+                if (COUNT) n_prims += 1;
+                if (s.kind == CRAY_SHAPE_TRIANGLE) {
+                    if (COUNT) n_tri += 1;
+                    double t, u, v;
+                    if (tri_test(mk(s.v0[0], s.v0[1], s.v0[2]), mk(s.e1[0], s.e1[1], s.e1[2]), mk(s.e2[0], s.e2[1], s.e2[2]), ray, t, u, v)) {
+                        if (ANY) { res.occluded = true; return res; }
+                        ray.tmax = t;  // Ray::update_max_distance
+                        res.t = t; res.u = u; res.v = v; res.prim = (int32_t)s.prim;
+                    }
+                } else {
+                    const cray_prim& pr = sc.prims[s.prim];
+                    bool hit = s.kind == CRAY_SHAPE_SPHERE ? sphere_hit(sc.spheres[pr.shape], ray, ANY, nullptr)
+                                                           : disk_hit(sc.disks[pr.shape], ray, ANY, nullptr);
+                    if (hit) {
+                        if (ANY) { res.occluded = true; return res; }
+                        res.t = ray.tmax; res.prim = (int32_t)s.prim;  // distance: ray.max_distance (primitive.rs:66)
+                    }
+                }
+            }
+        } else {
+            const InnerNode& nd = sc.inner[cur];
+            const double k0 = child_key(nd.lo0, nd.hi0, ray.o, ray.d);
+            const double k1 = child_key(nd.lo1, nd.hi1, ray.o, ray.d);
+            // bvh.rs:92-98: dir[axis] < 0 -> push left, push right => right is visited first
+            const bool right_first = comp(ray.d, (int)nd.axis) < 0.0;
+            const uint32_t near = right_first ? nd.ref1 : nd.ref0, far = right_first ? nd.ref0 : nd.ref1;
+            const double kn = right_first ? k1 : k0, kf = right_first ? k0 : k1;
+            const bool an = kn < ray.tmax, af = kf < ray.tmax;
+            if (COUNT && !ANY) n_nodes += 2;  // both children are popped and tested by the reference
+            if (COUNT && ANY) {
+                // count pops in the reference's order: near now, far when (if) it is popped
+                n_nodes += 1;
+                if (sp < kStackDepth) { sref[sp] = far; skey[sp] = kf; sp++; } else overflow = 1;
+                if (an) { cur = near; continue; }
+            } else {
+                if (an) {
+                    if (af) {
+                        if (sp < kStackDepth) { sref[sp] = far; skey[sp] = kf; sp++; } else overflow = 1;
+                    }
+                    cur = near;
+                    continue;
+                }
+                if (af) { cur = far; continue; }
+            }
+        }
+        // pop; a deferred child is re-tested against the current ray.tmax
+        for (;;) {
+            if (sp == 0) return res;
+            --sp;
+            if (COUNT && ANY) n_nodes += 1;
+            if (skey[sp] < ray.tmax) break;
+        }
+        cur = sref[sp];
+    }
+}
+
+// Scene::intersect / Scene::intersects over a queue of paths.
+//  ANY = false: ray = path segment (tmax = +inf); writes the hit record.
+//  ANY = true : ray = the path's shadow ray; adds the stored NEE term to L when unoccluded
+//               (path_integrator.rs:141-163).
+template <bool ANY, bool COUNT>
+__global__ void __launch_bounds__(kBlock) k_trace(DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
+                                                  const unsigned int* __restrict__ n_ptr, uint32_t n_fixed,
+                                                  const double* __restrict__ closest_tmax, Counters* ctr) {
+    const uint32_t n = n_ptr ? *n_ptr : n_fixed;
+    unsigned long long nodes = 0, prims = 0, tris = 0;
+    unsigned int overflow = 0;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t p = queue ? queue[i] : i;
+        ray_t ray;
+        if (ANY) {
+            ray.o = mk(ps.sox[p], ps.soy[p], ps.soz[p]);
+            ray.d = mk(ps.sdx[p], ps.sdy[p], ps.sdz[p]);
+            ray.tmax = ps.stmax[p];
+        } else {
+            ray.o = mk(ps.ox[p], ps.oy[p], ps.oz[p]);
+            ray.d = mk(ps.dx[p], ps.dy[p], ps.dz[p]);
+            ray.tmax = closest_tmax ? closest_tmax[p] : inf64();  // path segments are Ray::new -> +inf
+        }
+        TraceResult r = traverse<ANY, COUNT>(sc, ray, nodes, prims, tris, overflow);
+        if (ANY) {
+            if (!r.occluded) {
+                ps.lr[p] = ps.lr[p] + ps.cr[p];
+                ps.lg[p] = ps.lg[p] + ps.cg[p];
+                ps.lb[p] = ps.lb[p] + ps.cb[p];
+            }
+        } else {
+            ps.ht[p] = r.t; ps.hu[p] = r.u; ps.hv[p] = r.v; ps.hprim[p] = r.prim;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ANY ? &ctr->shadow_rays : &ctr->closest_rays, (unsigned long long)n);
+    if (COUNT) {
+        if (nodes) atomicAdd(ANY ? &ctr->shadow_nodes : &ctr->closest_nodes, nodes);
+        if (prims) atomicAdd(ANY ? &ctr->shadow_prims : &ctr->closest_prims, prims);
+        if (tris) atomicAdd(ANY ? &ctr->shadow_tri : &ctr->closest_tri, tris);
+    }
+    if (overflow) atomicAdd(&ctr->stack_overflow, 1ull);
+}
+
+// render_pixel up to the camera ray (craytracer.rs:148-156) for every path of a pass.
+// path p -> pixel pix_list[px0 + p / spp_pass], sample s_lo + p % spp_pass.
+__global__ void __launch_bounds__(kBlock) k_raygen(DevScene sc, PathState ps, const uint32_t* __restrict__ pix_list, uint32_t px0,
+                                                   uint32_t n_paths, uint32_t spp_pass, uint32_t s_lo, uint64_t seed) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n_paths; p += stride) {
+        const uint32_t pix = pix_list[px0 + p / spp_pass];
+        const uint32_t s = s_lo + p % spp_pass;
+        const uint32_t x = pix % sc.film_w, y = pix / sc.film_w;
+        const uint32_t h = pixel_seed(seed, x, y);  // SobolSampler::start_pixel
+        double u[4];
+        sobol4(sc.sobol, s, 0, h, u);  // dims 0,1 film; 2,3 lens (always drawn, craytracer.rs:153-154)
+        ray_t r = camera_ray(sc, u[0], u[1], u[2], u[3], x, y);
+        ps.ox[p] = r.o.x; ps.oy[p] = r.o.y; ps.oz[p] = r.o.z;
+        ps.dx[p] = r.d.x; ps.dy[p] = r.d.y; ps.dz[p] = r.d.z;
+        ps.br[p] = 1.0; ps.bg[p] = 1.0; ps.bb[p] = 1.0;
+        ps.lr[p] = 0.0; ps.lg[p] = 0.0; ps.lb[p] = 0.0;
+        ps.prev_pdf[p] = 0.0;
+        ps.hash[p] = h;
+        ps.flags[p] = 1u;  // is_specular_bounce = true for camera rays (path_integrator.rs:50)
+    }
+}
+
+// wave-aggregated append: one atomic per wave (ballot + popcount + lane prefix)
+__device__ __forceinline__ void queue_push(uint32_t* __restrict__ q, unsigned int* __restrict__ count, bool pred, uint32_t value) {
+    const unsigned long long mask = __ballot(pred);
+    if (mask == 0) return;
+    const unsigned int lane = __lane_id();
+    const unsigned int leader = __ffsll((long long)mask) - 1;
+    unsigned int base = 0;
+    if (lane == leader) base = atomicAdd(count, (unsigned int)__popcll(mask));
+    base = __shfl(base, leader);
+    if (pred) q[base + __popcll(mask & ((1ull << lane) - 1ull))] = value;
+}
+
+// The body of one estimate_Li iteration between the two BVH queries (path_integrator.rs:56-211).
+__global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
+                                                  const unsigned int* __restrict__ n_ptr, uint32_t n_fixed, uint32_t bounce,
+                                                  uint32_t spp_pass, uint32_t s_lo, uint32_t* __restrict__ next_queue,
+                                                  unsigned int* next_count, uint32_t* __restrict__ shadow_queue,
+                                                  unsigned int* shadow_count, Counters* ctr) {
+    const uint32_t n = n_ptr ? *n_ptr : n_fixed;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t n_round = (n + 63u) & ~63u;  // keep whole waves in the loop for the ballots
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+        bool want_shadow = false, want_next = false;
+        uint32_t p = 0;
+        if (i < n) {
+            p = queue ? queue[i] : i;
+            ray_t ray = mkray(mk(ps.ox[p], ps.oy[p], ps.oz[p]), mk(ps.dx[p], ps.dy[p], ps.dz[p]));
+            rgb L = mkc(ps.lr[p], ps.lg[p], ps.lb[p]);
+            rgb beta = mkc(ps.br[p], ps.bg[p], ps.bb[p]);
+            const double prev_pdf = ps.prev_pdf[p];
+            const bool specular_bounce = (ps.flags[p] & 1u) != 0;
+            const int32_t hp = ps.hprim[p];
+            const vec3 w_o = flip(ray.d);
+
+            if (hp < 0) {
+                // escaped: Light::Le is non-black only for Infinite lights (light.rs:161-168)
+                for (uint32_t li = 0; li < sc.n_lights; li++) {
+                    const DevLight& l = sc.lights[li];
+                    if (l.kind != CRAY_LIGHT_INFINITE) continue;
+                    rgb Le = mkc(l.c[0], l.c[1], l.c[2]);
+                    if (specular_bounce) {
+                        L = L + beta * Le;  // :64-67
+                    } else if (!black(Le)) {  // :68-88; pdf_Li of Infinite = 1/(4 pi) (light.rs:140)
+                        double light_pdf = (kInvPi / 4.0) * light_select_pdf(sc, li);
+                        double w = power_heuristic(light_pdf, prev_pdf);
+                        L = L + beta * Le * w;
+                    }
+                }
+                ps.lr[p] = L.r; ps.lg[p] = L.g; ps.lb[p] = L.b;
+            } else {
+                const cray_prim pr = sc.prims[hp];
+                const SurfPoint sp = surface_at(sc, pr, ray, ps.ht[p], ps.hu[p], ps.hv[p]);
+                const vec3 n_s = sp.normal, x = sp.location;
+                const int32_t mat = pr.light >= 0 ? -1 : pr.material;
+
+                // PathSegmentSamples::from (path_integrator.rs:26-36): dims 4+8k .. 11+8k
+                const uint32_t sidx = s_lo + p % spp_pass;
+                const uint32_t h = ps.hash[p];
+                double sa[4], sb[4];
+                sobol4(sc.sobol, sidx, 1 + 2 * bounce, h, sa);  // material 1D, material 2D, light index
+                sobol4(sc.sobol, sidx, 2 + 2 * bounce, h, sb);  // light 1D, light 2D, roulette
+
+                // emission at the hit (:106-126)
+                if (pr.light >= 0) {
+                    const DevLight& l = sc.lights[pr.light];
+                    rgb Le = mkc(l.c[0], l.c[1], l.c[2]);
+                    if (!black(Le)) {
+                        if (specular_bounce) {
+                            L = L + beta * Le;
+                        } else {
+                            double lp = light_shape_pdf_from(sc, l, x, n_s, w_o);
+                            double light_pdf = lp * light_select_pdf(sc, (uint32_t)sc.first_equal_light[pr.light]);
+                            double w = power_heuristic(light_pdf, prev_pdf);
+                            L = L + beta * Le * w;
+                        }
+                    }
+                }
+
+                // next-event estimation (:129-164): build the shadow ray and the term it gates
+                {
+                    double sel_pdf;
+                    const uint32_t li = light_select(sc, sa[3], sel_pdf);
+                    const DevLight& l = sc.lights[li];
+                    vec3 w_i;
+                    rgb Li = mkc(l.c[0], l.c[1], l.c[2]);
+                    double lpdf = 0.0, s_tmax = inf64();
+                    bool delta = false;
+                    if (l.kind == CRAY_LIGHT_POINT) {  // light.rs:65-79
+                        vec3 op = mk(l.v[0], l.v[1], l.v[2]) - x;
+                        double d2 = len2(op);
+                        double dist = sqrt(d2);
+                        w_i = op / dist;
+                        if (dist > kEps) s_tmax = dist;  // update_max_distance on a fresh ray
+                        Li = Li / d2;
+                        delta = true;
+                    } else if (l.kind == CRAY_LIGHT_DISTANT) {  // :80-96
+                        w_i = mk(l.v[0], l.v[1], l.v[2]);
+                        delta = true;
+                    } else if (l.kind == CRAY_LIGHT_INFINITE) {  // :97-113
+                        vec3 nn = sb[0] < 0.5 ? mk(1, 0, 0) : mk(-1, 0, 0);
+                        vec3 r = sample_sphere(sb[1], sb[2]);
+                        w_i = dot(r, nn) > 0.0 ? r : flip(r);  // sample_hemisphere
+                        lpdf = kInvPi / 4.0;
+                    } else {  // Area, :114-131 + Shape::sample_from (shape.rs:472-484)
+                        vec3 pt = light_shape_sample(sc, l, sb[1], sb[2]);
+                        w_i = unit(pt - x);
+                        lpdf = light_shape_pdf_from(sc, l, x, n_s, w_i);
+                        double dist = len(pt - x);
+                        double tm = dist - kEps;
+                        if (tm > kEps) s_tmax = tm;
+                    }
+                    rgb f = material_f(sc, mat, w_o, w_i, n_s, sp.u, sp.v);
+                    double cos_t = fabs(dot(w_i, n_s));
+                    rgb contrib = mkc(0, 0, 0);
+                    if (!delta) {
+                        if (lpdf > 0.0) {
+                            double light_pdf = lpdf * sel_pdf;
+                            double bsdf_pdf = 0.0;
+                            if (!material_pdf(sc, mat, w_o, w_i, n_s, bsdf_pdf)) bsdf_pdf = 0.0;
+                            double w = power_heuristic(light_pdf, bsdf_pdf);
+                            contrib = beta * Li * f * cos_t * w / light_pdf;
+                        }
+                    } else {
+                        contrib = beta * Li * f * cos_t / sel_pdf;
+                    }
+                    ps.sox[p] = x.x; ps.soy[p] = x.y; ps.soz[p] = x.z;
+                    ps.sdx[p] = w_i.x; ps.sdy[p] = w_i.y; ps.sdz[p] = w_i.z;
+                    ps.stmax[p] = s_tmax;
+                    ps.cr[p] = contrib.r; ps.cg[p] = contrib.g; ps.cb[p] = contrib.b;
+                    want_shadow = true;  // the reference queries Scene::intersects unconditionally (:141)
+                }
+
+                // BSDF sample, throughput update, roulette (:167-206)
+                LobeSample ls;
+                bool go = material_sample(sc, mat, sa[0], sa[1], sa[2], w_o, n_s, sp.u, sp.v, ls);
+                if (go && black(ls.f)) go = false;
+                double bsdf_pdf = 0.0;
+                if (go) {
+                    bsdf_pdf = ls.delta ? 1.0 : ls.pdf;
+                    if (bsdf_pdf == 0.0) go = false;
+                }
+                if (go) {
+                    double cos_t = fabs(dot(ls.w_i, n_s));
+                    beta = beta * ls.f * cos_t / bsdf_pdf;
+                    if (bounce > 0) {
+                        double m = max_nn(beta.r, max_nn(beta.g, beta.b));
+                        if (m < 1.0) {
+                            double q = 1.0 - m;
+                            if (sb[3] < q) go = false;
+                            else beta = beta / (1.0 - q);
+                        }
+                    }
+                }
+                if (go) {
+                    if (!finite3(beta)) atomicAdd(&ctr->nonfinite, 1ull);  // reference: assert!(beta.is_finite())
+                    // the loop condition of the next iteration (:54)
+                    go = (bounce + 1 < sc.max_depth) && !black(beta);
+                }
+                ps.lr[p] = L.r; ps.lg[p] = L.g; ps.lb[p] = L.b;
+                if (go) {
+                    ps.ox[p] = x.x; ps.oy[p] = x.y; ps.oz[p] = x.z;  // Ray::new(location, w_i): no offset
+                    ps.dx[p] = ls.w_i.x; ps.dy[p] = ls.w_i.y; ps.dz[p] = ls.w_i.z;
+                    ps.br[p] = beta.r; ps.bg[p] = beta.g; ps.bb[p] = beta.b;
+                    ps.prev_pdf[p] = bsdf_pdf;
+                    ps.flags[p] = ls.specular ? 1u : 0u;
+                    want_next = true;
+                }
+            }
+        }
+        queue_push(shadow_queue, shadow_count, want_shadow, p);
+        queue_push(next_queue, next_count, want_next, p);
+    }
+}
+
+// render_tile's accumulation (craytracer.rs:175-188): per pixel, each sample batch is summed in
+// f64 in sample order, cast to f32 and added into the f32 film; batches in ascending order.
+__global__ void __launch_bounds__(kBlock) k_film(PathState ps, const uint32_t* __restrict__ pix_list, uint32_t px0, uint32_t n_pix,
+                                                 uint32_t spp_pass, uint32_t s_lo, uint32_t batch, float* __restrict__ film, Counters* ctr) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t pl = blockIdx.x * blockDim.x + threadIdx.x; pl < n_pix; pl += stride) {
+        const uint32_t pix = pix_list[px0 + pl];
+        float fr = film[3 * (size_t)pix], fg = film[3 * (size_t)pix + 1], fb = film[3 * (size_t)pix + 2];
+        double cr = 0.0, cg = 0.0, cb = 0.0;
+        bool bad = false;
+        for (uint32_t j = 0; j < spp_pass; j++) {
+            const size_t p = (size_t)pl * spp_pass + j;
+            const double r = ps.lr[p], g = ps.lg[p], b = ps.lb[p];
+            if (!(isfinite(r) && isfinite(g) && isfinite(b))) bad = true;
+            cr += r; cg += g; cb += b;
+            const uint32_t s = s_lo + j;
+            if (((s + 1) % batch) == 0 || j + 1 == spp_pass) {
+                fr += (float)cr; fg += (float)cg; fb += (float)cb;
+                cr = 0.0; cg = 0.0; cb = 0.0;
+            }
+        }
+        film[3 * (size_t)pix] = fr; film[3 * (size_t)pix + 1] = fg; film[3 * (size_t)pix + 2] = fb;
+        if (bad) atomicAdd(&ctr->nonfinite, 1ull);
+    }
+}
+
+// on_finish (craytracer.rs:253-259): `*pixel /= num_samples as f32`
+__global__ void __launch_bounds__(kBlock) k_resolve(const float* __restrict__ film, float* __restrict__ out, size_t n, float num_samples) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = film[i] / num_samples;
+}
+
+// test hook: fill cray_hit records after a closest-hit trace of externally supplied rays
+__global__ void __launch_bounds__(kBlock) k_hit_records(DevScene sc, PathState ps, uint32_t n, cray_hit* __restrict__ hits) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+        cray_hit h;
+        h.hit = ps.hprim[p] >= 0 ? 1 : 0;
+        h.prim = ps.hprim[p];
+        h.t = ps.ht[p];
+        for (int k = 0; k < 3; k++) { h.location[k] = 0.0; h.normal[k] = 0.0; }
+        h.uv[0] = 0.0; h.uv[1] = 0.0;
+        if (h.hit) {
+            ray_t ray = mkray(mk(ps.ox[p], ps.oy[p], ps.oz[p]), mk(ps.dx[p], ps.dy[p], ps.dz[p]));
+            SurfPoint sp = surface_at(sc, sc.prims[h.prim], ray, ps.ht[p], ps.hu[p], ps.hv[p]);
+            h.location[0] = sp.location.x; h.location[1] = sp.location.y; h.location[2] = sp.location.z;
+            h.normal[0] = sp.normal.x; h.normal[1] = sp.normal.y; h.normal[2] = sp.normal.z;
+            h.uv[0] = sp.u; h.uv[1] = sp.v;
+        }
+        hits[p] = h;
+    }
+}
+
+}  // namespace cray

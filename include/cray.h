@@ -1,0 +1,159 @@
+/*
+ * cray.h — C ABI of the MI355X render backend for craytracer's hot path.
+ *
+ * The reference has no FFI; the seam this library replaces is the body of
+ *     fn render(scene: &Scene, sampler: SobolSampler, ..) -> Vec<f32>
+ * (reference src/bin/craytracer.rs:224-319, output contract :253-259: W*H*3 f32,
+ * row-major, y down, RGB interleaved, already divided by num_samples), plus the
+ * finer seams Scene::intersect / Scene::intersects (src/scene.rs:55-61) as a
+ * test hook.  INTEGRATION.md shows the Rust `extern "C"` block that binds it.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; the caller owns every pointer it passes;
+ *    the library copies what it needs during cray_scene_upload.
+ *  - every call returns 0 on success or a negative CRAY_ERR_* code;
+ *    cray_last_error() gives a thread-local message.  Nothing aborts or throws
+ *    across the ABI: the reference's hot-path panics become
+ *    counters in cray_stats.
+ *  - one host thread per cray_ctx at a time; one process per GPU (multi-GPU =
+ *    one ctx per rank, tiles sharded by (rank, world) in cray_render_params).
+ */
+#ifndef CRAY_H
+#define CRAY_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "cray_scene_desc.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRAY_ABI_VERSION 1
+
+enum {
+    CRAY_OK = 0,
+    CRAY_ERR_INVALID = -1,      /* bad argument / inconsistent scene */
+    CRAY_ERR_HIP = -2,          /* HIP runtime error (message has the detail) */
+    CRAY_ERR_UNSUPPORTED = -3,  /* e.g. BVH leaf with more than 8 primitives, depth > 31 */
+    CRAY_ERR_NO_DEVICE = -4,
+    CRAY_ERR_BUILD = -5         /* Bvh::new would have panicked (bvh.rs:245,304,327-328) */
+};
+
+/* ---- flattened Scene: what a host-side `Scene::flatten()` hands over ------ */
+
+/* BvhNode (src/bvh.rs:13-24) in DFS pre-order; node 0 is the root. */
+typedef struct {
+    double bmin[3], bmax[3];    /* Bounds */
+    uint32_t left, right;       /* InteriorNode children (indices into nodes[]) */
+    uint32_t first, count;      /* LeafNode: prim_refs[first .. first+count) in the leaf's own order */
+    int32_t axis;               /* InteriorNode split_axis: 0 X, 1 Y, 2 Z */
+    int32_t is_leaf;
+} cray_bvh_node;
+
+/* Sphere / Disk with their Transformation pair resolved (src/shape.rs:55-69,133-153):
+ * m = object_to_world.matrix, inv = object_to_world.inverse (== world_to_object.matrix). */
+typedef struct {
+    double m[16], inv[16];
+    double radius, inner_radius;
+} cray_xf_shape;
+
+typedef struct {
+    uint32_t abi_version;       /* CRAY_ABI_VERSION */
+    /* Scene fields (src/scene.rs:15-23) */
+    uint32_t max_depth, num_samples;
+    /* Camera (src/camera.rs:16-23) */
+    int32_t camera_type;
+    uint32_t film_width, film_height;
+    double camera_from_raster[16];  /* row-major Transformation.matrix */
+    double world_from_camera[16];
+    double lens_radius, focal_distance;
+    /* Bvh (src/bvh.rs:31-35) */
+    uint32_t n_nodes;     const cray_bvh_node* nodes;
+    uint32_t n_prim_refs; const uint32_t* prim_refs;
+    /* primitives / shapes */
+    uint32_t n_prims;     const cray_prim* prims;
+    uint32_t n_triangles; const cray_triangle* triangles;
+    uint32_t n_spheres;   const cray_xf_shape* spheres;
+    uint32_t n_disks;     const cray_xf_shape* disks;
+    /* materials */
+    uint32_t n_materials; const cray_material* materials;
+    uint32_t n_bxdfs;     const cray_bxdf* bxdfs;
+    uint32_t n_textures;  const cray_texture* textures;
+    uint32_t n_images;    const cray_image* images;
+    uint64_t image_pool_bytes; const uint8_t* image_pool;
+    /* lights + LightSampler (src/light.rs:182-220) */
+    uint32_t n_lights;    const cray_light* lights;
+    const double* light_cdf;            /* LightSampler.cdfs, n_lights entries */
+    const int32_t* first_equal_light;   /* lights.iter().position(|l| l == light), path_integrator.rs:116 */
+} cray_flat_scene;
+
+/* ---- render ----------------------------------------------------------------- */
+typedef struct {
+    uint64_t seed;              /* SobolSampler::new(seed, ..), craytracer.rs:361; Cli.seed :332-333 */
+    uint32_t tile_width;        /* 64  (craytracer.rs:232) */
+    uint32_t tile_height;       /* 64  (craytracer.rs:233) */
+    uint32_t sample_batch;      /* 8   (craytracer.rs:234): f64 sum of a batch -> f32 add into the film */
+    uint32_t rank, world_size;  /* this ctx renders tiles with tile_index % world_size == rank;
+                                   pixels of other tiles are left 0 in out_rgb. (0,1) = whole film */
+    uint32_t sample_begin, sample_end; /* render samples [begin,end); (0,0) = all. Always divides by num_samples */
+    uint32_t out_is_device;     /* 0: out_rgb is host memory; 1: device memory on the ctx's GPU */
+    uint32_t count_traversal;   /* 1: also count BVH nodes / primitive tests (cray_stats) */
+    uint64_t max_paths_in_flight; /* 0 = default */
+} cray_render_params;
+
+typedef struct {
+    uint64_t paths;                         /* W*H*spp rendered by this call */
+    uint64_t closest_rays, shadow_rays;     /* Scene::intersect / Scene::intersects calls */
+    uint64_t closest_nodes, closest_prims;  /* nodes popped / primitives tested (count_traversal) */
+    uint64_t shadow_nodes, shadow_prims;
+    uint64_t closest_tri_tests, shadow_tri_tests;
+    uint64_t nonfinite;                     /* paths where the reference's assert!(is_finite) would fire */
+    uint64_t stack_overflow;                /* traversal stack overflows (must be 0) */
+    double seconds;                         /* first launch -> film complete, host clock around a device sync */
+    double trace_closest_ms, trace_any_ms, shade_ms, other_ms; /* HIP-event time per kernel family */
+    uint32_t trace_closest_launches, trace_any_launches, shade_launches, pad_;
+} cray_stats;
+
+/* test hook: batched Scene::intersect / Scene::intersects */
+typedef struct { double o[3], d[3], tmax; } cray_ray;
+typedef struct {
+    int32_t hit;        /* 0/1 */
+    int32_t prim;       /* index into prims[], -1 on miss (closest only) */
+    double t;           /* PrimitiveIntersection.distance */
+    double location[3], normal[3], uv[2];
+} cray_hit;
+
+typedef struct cray_ctx cray_ctx;
+typedef struct cray_scene cray_scene;
+
+/* Create a context on HIP device `device_id`. `stream` is a hipStream_t to launch on
+ * (e.g. torch's current stream) or NULL for a stream owned by the context. */
+int cray_ctx_create(int device_id, void* stream, cray_ctx** out);
+void cray_ctx_destroy(cray_ctx* ctx);
+
+/* Copy a flattened scene into HBM in the device layout (DESIGN.md "Data layout"). */
+int cray_scene_upload(cray_ctx* ctx, const cray_flat_scene* scene, cray_scene** out);
+void cray_scene_free(cray_scene* scene);
+uint64_t cray_scene_device_bytes(const cray_scene* scene);
+
+/* Replaces `render` (craytracer.rs:224): fills out_rgb[W*H*3]. */
+int cray_render(cray_ctx* ctx, cray_scene* scene, const cray_render_params* params, float* out_rgb,
+                cray_stats* stats);
+void cray_render_params_default(cray_render_params* params);
+
+/* Per-path radiance of one sample batch, for per-sample parity checks:
+ * out_L[(y*W + x)*n + (s - sample_begin)][3] f64, host memory. */
+int cray_render_samples(cray_ctx* ctx, cray_scene* scene, const cray_render_params* params, double* out_L);
+
+/* Replaces Scene::intersect (any_hit = 0) / Scene::intersects (any_hit = 1), scene.rs:55-61. */
+int cray_trace(cray_ctx* ctx, cray_scene* scene, const cray_ray* rays, size_t n, cray_hit* hits, int any_hit,
+               cray_stats* stats);
+
+const char* cray_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRAY_H */

@@ -1,0 +1,40 @@
+/*
+ * cray_host.h — C ABI of the host-side mirror of `Scene::new`.
+ *
+ * In a Rust deployment the host keeps craytracer's own Scene/Camera/Bvh code and
+ * only adds a `flatten()`.  Rust is not available in this build
+ * environment, so the same host logic exists here in C++:
+ *   Scene::new                src/scene.rs:25-53
+ *   Bvh::new (SAH / median)   src/bvh.rs:38-56, 191-336, util::partition_by src/util.rs:4-26
+ *   Shape constructors/bounds src/shape.rs:55-69, 133-153, 402-438
+ *   Camera::new               src/camera.rs:25-76
+ *   LightSampler::new         src/light.rs:187-200, Light::power :170-177
+ * and produces the `cray_flat_scene` that cray_scene_upload (cray.h) consumes.
+ */
+#ifndef CRAY_HOST_H
+#define CRAY_HOST_H
+
+#include "cray.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { CRAY_SPLIT_MEDIAN = 0, CRAY_SPLIT_SAH = 1 }; /* bvh.rs:26-29; Scene::new uses SAH (scene.rs:38) */
+
+typedef struct cray_host_scene cray_host_scene;
+
+/* Returns CRAY_ERR_BUILD where the reference would panic while building (zero surface
+ * area, empty side after partition, no primitives); CRAY_ERR_INVALID for "No lights in
+ * the scene." (scene_parser.rs:1104-1109) and bad indices. */
+int cray_host_scene_new(const cray_scene_desc* desc, int split_method, cray_host_scene** out);
+/* The flat view stays valid until cray_host_scene_free; it borrows the desc's
+ * material/texture/image/triangle arrays, which must outlive it too. */
+const cray_flat_scene* cray_host_scene_flat(const cray_host_scene* scene);
+double cray_host_scene_build_seconds(const cray_host_scene* scene);
+void cray_host_scene_free(cray_host_scene* scene);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

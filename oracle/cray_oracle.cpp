@@ -1101,7 +1101,9 @@ static Ray camera_sample(const Scene& sc, double fx, double fy, double lx, doubl
 /* ======================================================================== */
 /* path_integrator::estimate_Li, src/path_integrator.rs:41-215                */
 /* ======================================================================== */
-static Col estimate_Li(const Scene& sc, Sampler& sampler, Ray ray, Stats* st) {
+/* `log` (optional, tests only): 20 doubles per loop iteration that reaches a hit:
+ * prim, t, location[3], normal[3], shadow_occluded, L[3] after NEE, w_i[3], beta[3], continued, nee_light_pdf */
+static Col estimate_Li(const Scene& sc, Sampler& sampler, Ray ray, Stats* st, double* log = nullptr, int log_cap = 0, int* log_n = nullptr) {
     Col L = BLACK, beta = WHITE;
     uint32_t bounces = 0;
     bool is_specular_bounce = true;
@@ -1160,13 +1162,23 @@ static Col estimate_Li(const Scene& sc, Sampler& sampler, Ray ray, Stats* st) {
             }
         }
 
+        double* rec = (log && log_n && *log_n < log_cap) ? log + 20 * (*log_n) : nullptr;
+        if (rec) {
+            for (int k = 0; k < 20; k++) rec[k] = 0.0;
+            rec[0] = (double)isect.prim; rec[1] = isect.distance;
+            rec[2] = location.x; rec[3] = location.y; rec[4] = location.z;
+            rec[5] = normal.x; rec[6] = normal.y; rec[7] = normal.z;
+            *log_n += 1;
+        }
         /* next-event estimation, :129-164 */
         {
             double light_sampler_pdf_v;
             size_t light_index = light_sampler_sample(sc, li_idx, &light_sampler_pdf_v);
             const Light& light = sc.lights[light_index];
             LightSample ls = light_sample_Li(sc, light, l1, l2a, l2b, location, normal);
-            if (!bvh_intersects(sc, ls.shadow_ray, st)) {
+            bool occluded = bvh_intersects(sc, ls.shadow_ray, st);
+            if (rec) { rec[8] = occluded ? 1.0 : 0.0; rec[19] = ls.pdf; }
+            if (!occluded) {
                 Col f = material_f(sc, material, w_o, ls.w_i, normal, tu, tv);
                 double cos_theta = std::fabs(dot(ls.w_i, normal));
                 if (!ls.delta) {
@@ -1184,6 +1196,7 @@ static Col estimate_Li(const Scene& sc, Sampler& sampler, Ray ray, Stats* st) {
             }
         }
 
+        if (rec) { rec[9] = L.r; rec[10] = L.g; rec[11] = L.b; }
         /* BSDF sampling, :167-195 */
         {
             SurfaceSample ss;
@@ -1197,6 +1210,7 @@ static Col estimate_Li(const Scene& sc, Sampler& sampler, Ray ray, Stats* st) {
             is_specular_bounce = ss.is_specular;
             prev_bsdf_pdf = bsdf_pdf;
             prev_loc = location; prev_normal = normal;
+            if (rec) { rec[12] = ss.w_i.x; rec[13] = ss.w_i.y; rec[14] = ss.w_i.z; rec[15] = beta.r; rec[16] = beta.g; rec[17] = beta.b; rec[18] = 1.0; }
         }
 
         /* Russian roulette, :197-206 */
@@ -1452,6 +1466,19 @@ void orc_render_pixel(void* s, uint64_t seed, uint32_t x, uint32_t y, uint32_t s
     Stats st; memset(&st, 0, sizeof(st));
     Col c = render_pixel(*sc, sampler, x, y, sample, &st);
     L[0] = c.r; L[1] = c.g; L[2] = c.b;
+}
+/* test-only: per-bounce log of one path (see estimate_Li) */
+int orc_path_log(void* s, uint64_t seed, uint32_t x, uint32_t y, uint32_t sample, double* rec, int cap) {
+    Scene* sc = (Scene*)s;
+    Sampler sampler; sampler.seed = seed;
+    Stats st; memset(&st, 0, sizeof(st));
+    sampler.start_pixel(x, y, sample);
+    double fx, fy, lx, ly;
+    sampler.sample_2d(&fx, &fy); sampler.sample_2d(&lx, &ly);
+    Ray ray = camera_sample(*sc, fx, fy, lx, ly, x, y);
+    int n = 0;
+    estimate_Li(*sc, sampler, ray, &st, rec, cap, &n);
+    return n;
 }
 /* Camera ray of (x, y, sample): {o[3], d[3], tmax} */
 void orc_camera_ray(void* s, uint64_t seed, uint32_t x, uint32_t y, uint32_t sample, double* ray7) {

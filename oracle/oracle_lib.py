@@ -61,6 +61,7 @@ def lib():
         L.orc_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_render.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_render_pixel.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_path_log.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int]
         L.orc_camera_ray.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_siphash.restype = C.c_uint64
         L.orc_siphash.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
@@ -149,6 +150,11 @@ class OracleScene:
         L = np.zeros(3)
         lib().orc_render_pixel(self._h, seed, x, y, sample, L.ctypes.data)
         return L
+
+    def path_log(self, x, y, sample, seed=0, cap=40):
+        rec = np.zeros((cap, 20))
+        n = lib().orc_path_log(self._h, seed, x, y, sample, rec.ctypes.data, cap)
+        return rec[:n]
 
     def camera_ray(self, x, y, sample, seed=0):
         r = np.zeros(7)
