@@ -90,7 +90,7 @@ int upload(cray_scene* s, const T* host, size_t n, const T** out) {
 
 int ensure_state(cray_ctx* c, size_t capacity) {
     if (c->capacity >= capacity) return CRAY_OK;
-    for (void* p : c->state_allocs) hipFree(p);
+    for (void* p : c->state_allocs) (void)hipFree(p);
     c->state_allocs.clear();
     c->capacity = 0;
     auto alloc = [&](size_t bytes, void** out) -> int {
@@ -186,7 +186,7 @@ extern "C" int cray_ctx_create(int device_id, void* stream, cray_ctx** out) {
     HIP_TRY(hipGetDeviceProperties(&prop, device_id));
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
-    else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    else { HIP_TRY(hipStreamCreate(&c->stream)); c->own_stream = true; }
     HIP_TRY(hipMalloc((void**)&c->counters, sizeof(Counters)));
     *out = c;
     return CRAY_OK;
@@ -194,20 +194,20 @@ extern "C" int cray_ctx_create(int device_id, void* stream, cray_ctx** out) {
 
 extern "C" void cray_ctx_destroy(cray_ctx* c) {
     if (!c) return;
-    hipSetDevice(c->device);
-    for (void* p : c->state_allocs) hipFree(p);
-    if (c->counters) hipFree(c->counters);
-    if (c->pix_list) hipFree(c->pix_list);
-    if (c->film) hipFree(c->film);
-    for (hipEvent_t e : c->events) hipEventDestroy(e);
-    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    (void)hipSetDevice(c->device);
+    for (void* p : c->state_allocs) (void)hipFree(p);
+    if (c->counters) (void)hipFree(c->counters);
+    if (c->pix_list) (void)hipFree(c->pix_list);
+    if (c->film) (void)hipFree(c->film);
+    for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
 extern "C" void cray_scene_free(cray_scene* s) {
     if (!s) return;
-    if (s->ctx) hipSetDevice(s->ctx->device);
-    for (void* p : s->allocs) hipFree(p);
+    if (s->ctx) (void)hipSetDevice(s->ctx->device);
+    for (void* p : s->allocs) (void)hipFree(p);
     delete s;
 }
 extern "C" uint64_t cray_scene_device_bytes(const cray_scene* s) { return s ? s->bytes : 0; }
@@ -481,14 +481,14 @@ extern "C" int cray_render(cray_ctx* c, cray_scene* s, const cray_render_params*
 
     std::vector<uint32_t> pix = rank_pixels(W, H, *prm);
     if (pix.size() > c->pix_capacity) {
-        if (c->pix_list) hipFree(c->pix_list);
+        if (c->pix_list) (void)hipFree(c->pix_list);
         c->pix_list = nullptr; c->pix_capacity = 0;
         HIP_TRY(hipMalloc((void**)&c->pix_list, pix.size() * 4));
         c->pix_capacity = pix.size();
     }
     const size_t film_floats = (size_t)W * H * 3;
     if (film_floats > c->film_floats) {
-        if (c->film) hipFree(c->film);
+        if (c->film) (void)hipFree(c->film);
         c->film = nullptr; c->film_floats = 0;
         HIP_TRY(hipMalloc((void**)&c->film, film_floats * sizeof(float)));
         c->film_floats = film_floats;
@@ -522,7 +522,7 @@ extern "C" int cray_render(cray_ctx* c, cray_scene* s, const cray_render_params*
     hipError_t err = hipStreamSynchronize(c->stream);
     auto t1 = std::chrono::steady_clock::now();
     if (err == hipSuccess && staging) err = hipMemcpy(out_rgb, staging, film_floats * sizeof(float), hipMemcpyDeviceToHost);
-    if (staging) hipFree(staging);
+    if (staging) (void)hipFree(staging);
     if (err != hipSuccess) { set_last_error("render failed: %s", hipGetErrorString(err)); return CRAY_ERR_HIP; }
 
     if (stats) {
@@ -558,14 +558,14 @@ extern "C" int cray_render_samples(cray_ctx* c, cray_scene* s, const cray_render
     std::vector<uint32_t> pix(n_pix);
     for (size_t i = 0; i < n_pix; i++) pix[i] = (uint32_t)i;
     if (pix.size() > c->pix_capacity) {
-        if (c->pix_list) hipFree(c->pix_list);
+        if (c->pix_list) (void)hipFree(c->pix_list);
         c->pix_list = nullptr; c->pix_capacity = 0;
         HIP_TRY(hipMalloc((void**)&c->pix_list, pix.size() * 4));
         c->pix_capacity = pix.size();
     }
     const size_t film_floats = n_pix * 3;
     if (film_floats > c->film_floats) {
-        if (c->film) hipFree(c->film);
+        if (c->film) (void)hipFree(c->film);
         c->film = nullptr; c->film_floats = 0;
         HIP_TRY(hipMalloc((void**)&c->film, film_floats * sizeof(float)));
         c->film_floats = film_floats;
@@ -638,7 +638,7 @@ extern "C" int cray_trace(cray_ctx* c, cray_scene* s, const cray_ray* rays, size
         hipLaunchKernelGGL(k_hit_records, dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (uint32_t)n, d_hits);
         hipError_t err = hipStreamSynchronize(c->stream);
         if (err == hipSuccess) err = hipMemcpy(hits, d_hits, n * sizeof(cray_hit), hipMemcpyDeviceToHost);
-        hipFree(d_hits);
+        (void)hipFree(d_hits);
         if (err != hipSuccess) { set_last_error("cray_trace failed: %s", hipGetErrorString(err)); return CRAY_ERR_HIP; }
     }
     if (stats) {

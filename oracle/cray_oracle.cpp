@@ -226,9 +226,12 @@ static inline V3 cosine_sample_hemisphere(double u, double v, V3 normal, int* as
 /* ======================================================================== */
 /* Scene data                                                                 */
 /* ======================================================================== */
+struct XfPair { Xf o2w, w2o; };
+/* A Shape as stored per primitive.  Sphere/Disk transformations live behind a pointer so that a
+ * 7.2 M-triangle scene does not carry four unused matrices per triangle. */
 struct Shape {
     int kind;
-    Xf o2w, w2o; /* sphere / disk */
+    const XfPair* xf; /* sphere / disk */
     double radius, inner_radius;
     cray_triangle tri;
 };
@@ -294,16 +297,20 @@ static Shape make_sphere(V3 o, double radius) {
     Shape s; memset(&s, 0, sizeof(s));
     s.kind = CRAY_SHAPE_SPHERE;
     s.radius = radius;
-    s.o2w = xf_translate(o.x, o.y, o.z);
-    s.w2o = xf_translate(-o.x, -o.y, -o.z);
+    XfPair* x = new XfPair(); /* lives as long as the process: a handful per scene */
+    x->o2w = xf_translate(o.x, o.y, o.z);
+    x->w2o = xf_translate(-o.x, -o.y, -o.z);
+    s.xf = x;
     return s;
 }
 static Shape make_disk(V3 o, double rx, double ry, double radius, double inner) {
     Shape s; memset(&s, 0, sizeof(s));
     s.kind = CRAY_SHAPE_DISK;
     s.radius = radius; s.inner_radius = inner;
-    s.o2w = xf_mul(xf_mul(xf_translate(o.x, o.y, o.z), xf_rotate_x(to_radians(rx))), xf_rotate_y(to_radians(ry)));
-    s.w2o = xf_inverse(s.o2w);
+    XfPair* x = new XfPair();
+    x->o2w = xf_mul(xf_mul(xf_translate(o.x, o.y, o.z), xf_rotate_x(to_radians(rx))), xf_rotate_y(to_radians(ry)));
+    x->w2o = xf_inverse(x->o2w);
+    s.xf = x;
     return s;
 }
 static inline V3 cv(const cray_vec3& a) { return v3(a.x, a.y, a.z); }
@@ -312,7 +319,7 @@ static inline Col cc(const cray_color& a) { return col(a.r, a.g, a.b); }
 /* Shape::intersect, src/shape.rs:157-311. Mutates ray.tmax on acceptance. */
 static bool shape_intersect(const Shape& s, Ray& ray, Hit* h) {
     if (s.kind == CRAY_SHAPE_SPHERE) { /* :159-215 */
-        Ray obj = xf_ray(s.w2o, ray);
+        Ray obj = xf_ray(s.xf->w2o, ray);
         V3 oc = obj.o;
         double a = magnitude_squared(obj.d);
         double b = 2.0 * dot(oc, obj.d);
@@ -332,8 +339,8 @@ static bool shape_intersect(const Shape& s, Ray& ray, Hit* h) {
                 double u = phi / (PI * 2.0);
                 double theta = std::acos(loc.z / s.radius);
                 double v = theta * FRAC_1_PI;
-                h->location = xf_point(s.o2w, loc);
-                h->normal = xf_normal(s.o2w, loc / s.radius);
+                h->location = xf_point(s.xf->o2w, loc);
+                h->normal = xf_normal(s.xf->o2w, loc / s.radius);
                 h->u = u; h->v = v;
                 return true;
             }
@@ -361,7 +368,7 @@ static bool shape_intersect(const Shape& s, Ray& ray, Hit* h) {
         }
         return false;
     } else { /* Disk, :263-309 */
-        Ray obj = xf_ray(s.w2o, ray);
+        Ray obj = xf_ray(s.xf->w2o, ray);
         if (obj.d.z == 0.0) return false;
         double t = -obj.o.z / obj.d.z;
         if (!contains_distance(obj, t)) return false;
@@ -373,8 +380,8 @@ static bool shape_intersect(const Shape& s, Ray& ray, Hit* h) {
         double u = theta / (PI * 2.0);
         double v = std::sqrt(d2) / s.radius;
         if (update_max_distance(ray, t)) {
-            h->location = xf_point(s.o2w, loc);
-            h->normal = xf_normal(s.o2w, v3(0.0, 0.0, 1.0));
+            h->location = xf_point(s.xf->o2w, loc);
+            h->normal = xf_normal(s.xf->o2w, v3(0.0, 0.0, 1.0));
             h->u = u; h->v = v;
             return true;
         }
@@ -385,7 +392,7 @@ static bool shape_intersect(const Shape& s, Ray& ray, Hit* h) {
 /* Shape::intersects, src/shape.rs:314-400 */
 static bool shape_intersects(const Shape& s, const Ray& ray) {
     if (s.kind == CRAY_SHAPE_SPHERE) {
-        Ray obj = xf_ray(s.w2o, ray);
+        Ray obj = xf_ray(s.xf->w2o, ray);
         V3 oc = obj.o;
         double a = magnitude_squared(obj.d);
         double b = 2.0 * dot(oc, obj.d);
@@ -413,7 +420,7 @@ static bool shape_intersects(const Shape& s, const Ray& ray) {
         double distance = dot(cross(T, e1), e2) / denom;
         return contains_distance(ray, distance);
     } else {
-        Ray obj = xf_ray(s.w2o, ray);
+        Ray obj = xf_ray(s.xf->w2o, ray);
         if (obj.d.z == 0.0) return false;
         double t = -obj.o.z / obj.d.z;
         if (!contains_distance(obj, t)) return false;
@@ -428,7 +435,7 @@ static bool shape_intersects(const Shape& s, const Ray& ray) {
 static Bounds shape_bounds(const Shape& s) {
     if (s.kind == CRAY_SHAPE_SPHERE) {
         double r = s.radius;
-        return xf_bounds(s.o2w, bounds_new(v3(-r, -r, -r), v3(r, r, r)));
+        return xf_bounds(s.xf->o2w, bounds_new(v3(-r, -r, -r), v3(r, r, r)));
     } else if (s.kind == CRAY_SHAPE_TRIANGLE) {
         V3 v0 = cv(s.tri.v0);
         V3 v1 = v0 + cv(s.tri.e1), v2 = v0 + cv(s.tri.e2);
@@ -436,7 +443,7 @@ static Bounds shape_bounds(const Shape& s) {
                           v3(rmax(v1.x, rmax(v2.x, v0.x)), rmax(v1.y, rmax(v2.y, v0.y)), rmax(v1.z, rmax(v2.z, v0.z))));
     } else {
         double r = s.radius;
-        return xf_bounds(s.o2w, bounds_new(v3(-r, -r, 0.0), v3(r, r, 0.0)));
+        return xf_bounds(s.xf->o2w, bounds_new(v3(-r, -r, 0.0), v3(r, r, 0.0)));
     }
 }
 
@@ -451,7 +458,7 @@ static double shape_area(const Shape& s) {
 static V3 shape_sample(const Shape& s, double u, double v) {
     if (s.kind == CRAY_SHAPE_SPHERE) {
         V3 p = v3(0, 0, 0) + sample_sphere(u, v) * s.radius;
-        return xf_point(s.o2w, p);
+        return xf_point(s.xf->o2w, p);
     } else if (s.kind == CRAY_SHAPE_TRIANGLE) {
         double b1, b2;
         sample_triangle(u, v, &b1, &b2);
@@ -459,7 +466,7 @@ static V3 shape_sample(const Shape& s, double u, double v) {
     } else {
         double x, y;
         sample_disk(u, v, &x, &y);
-        return xf_point(s.o2w, v3(x * s.radius, y * s.radius, 0.0));
+        return xf_point(s.xf->o2w, v3(x * s.radius, y * s.radius, 0.0));
     }
 }
 
@@ -1299,7 +1306,7 @@ static Scene* scene_create(const cray_scene_desc* d, int split_method) {
                 } else {
                     key.push_back(sh.radius);
                     if (sh.kind == CRAY_SHAPE_DISK) key.push_back(sh.inner_radius);
-                    const Mat* ms[4] = {&sh.o2w.matrix, &sh.o2w.inverse, &sh.w2o.matrix, &sh.w2o.inverse};
+                    const Mat* ms[4] = {&sh.xf->o2w.matrix, &sh.xf->o2w.inverse, &sh.xf->w2o.matrix, &sh.xf->w2o.inverse};
                     for (int k = 0; k < 4; k++) for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) key.push_back(ms[k]->m[a][b]);
                 }
             }
