@@ -68,7 +68,7 @@ class FlatScene(C.Structure):
 ABI_SYMBOLS = ['cray_ctx_create', 'cray_ctx_destroy', 'cray_scene_upload', 'cray_scene_free',
                'cray_scene_device_bytes', 'cray_render', 'cray_render_params_default', 'cray_render_samples',
                'cray_trace', 'cray_last_error', 'cray_host_scene_new', 'cray_host_scene_flat',
-               'cray_host_scene_build_seconds', 'cray_host_scene_free']
+               'cray_host_scene_build_seconds', 'cray_host_scene_free', 'cray_host_sincos']
 
 _lib = None
 
@@ -106,6 +106,7 @@ def lib():
     L.cray_host_scene_build_seconds.restype = C.c_double
     L.cray_host_scene_build_seconds.argtypes = [C.c_void_p]
     L.cray_host_scene_free.argtypes = [C.c_void_p]
+    L.cray_host_sincos.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     _lib = L
     return L
 

@@ -500,3 +500,10 @@ extern "C" int cray_host_scene_new(const cray_scene_desc* d, int split_method, c
 extern "C" const cray_flat_scene* cray_host_scene_flat(const cray_host_scene* s) { return s ? &s->flat : nullptr; }
 extern "C" double cray_host_scene_build_seconds(const cray_host_scene* s) { return s ? s->build_seconds : 0.0; }
 extern "C" void cray_host_scene_free(cray_host_scene* s) { delete s; }
+
+extern "C" void cray_host_sincos(double x, double* s, double* c) {
+    double sv, cv;
+    cray::sincos_cr(x, sv, cv);
+    if (s) *s = sv;
+    if (c) *c = cv;
+}

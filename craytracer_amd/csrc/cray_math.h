@@ -141,3 +141,98 @@ CRAY_HD ray_t xf_ray(const double* m, const ray_t& r) {  // :456-462
 }
 
 }  // namespace cray
+
+// -----------------------------------------------------------------------------------------
+// Correctly rounded sin / cos for the sampling routines (sample_disk, sample_sphere).
+//
+// Rust documents f64::sin/cos as platform-precision ("non-deterministic"): on Linux they are
+// glibc's (which misrounds ~0.15 % of calls and has an FMA ifunc variant), different in the last
+// bit from every other libm.  The reference's shadow-ray leak (scenes/rounding-error.cry)
+// amplifies such a 1-ulp difference into a visibly different path about once per 3000 paths.
+// To make "same inputs -> same pixels" well defined, the test oracle rounds sin/cos correctly
+// (through binary128) and so does this routine: double-double evaluation (~2^-100 relative),
+// one final rounding.  Only fma() and + - * are used, so host and gfx950 agree bit for bit.
+// Valid for |x| <= 16; the callers stay within [-pi/4, 2 pi].
+// Constants generated exactly (tools: see DESIGN.md "libm").
+// -----------------------------------------------------------------------------------------
+namespace cray {
+struct dd {
+    double hi, lo;
+};
+CRAY_HD dd dd_two_sum(double a, double b) {
+    double s = a + b, bb = s - a;
+    return dd{s, (a - (s - bb)) + (b - bb)};
+}
+CRAY_HD dd dd_quick_two_sum(double a, double b) {
+    double s = a + b;
+    return dd{s, b - (s - a)};
+}
+CRAY_HD dd dd_two_prod(double a, double b) {
+    double p = a * b;
+    return dd{p, fma(a, b, -p)};
+}
+CRAY_HD dd dd_add(dd a, dd b) {
+    dd s = dd_two_sum(a.hi, b.hi), t = dd_two_sum(a.lo, b.lo);
+    s.lo += t.hi;
+    s = dd_quick_two_sum(s.hi, s.lo);
+    s.lo += t.lo;
+    return dd_quick_two_sum(s.hi, s.lo);
+}
+CRAY_HD dd dd_mul(dd a, dd b) {
+    dd p = dd_two_prod(a.hi, b.hi);
+    p.lo += a.hi * b.lo + a.lo * b.hi;
+    return dd_quick_two_sum(p.hi, p.lo);
+}
+
+CRAY_HD void sincos_cr(double x, double& s_out, double& c_out) {
+    // pi/2 = P1 + P2 + P3 + P4; P1..P3 carry 33 significant bits, so k * Pi is exact for |k| < 2^20
+    const double P1 = 0x1.921fb54400000p+0, P2 = 0x1.0b4611a600000p-34, P3 = 0x1.3198a2e000000p-69, P4 = 0x1.b839a252049c1p-104;
+    const double k = rint(x * 0x1.45f306dc9c883p-1);  // nearest multiple of pi/2
+    const double t = x - k * P1;    // exact: Sterbenz for k != 0
+    dd r = dd_two_sum(t, -(k * P2));
+    r = dd_add(r, dd{-(k * P3), 0.0});
+    r = dd_add(r, dd{-(k * P4), 0.0});
+    const dd r2 = dd_mul(r, r);
+    // (-1)^j / (2j+1)!  and  (-1)^j / (2j)!  as double-doubles
+    const double S[14][2] = {
+        {0x1.0000000000000p+0, 0x0.0p+0},
+        {-0x1.5555555555555p-3, -0x1.5555555555555p-57},
+        {0x1.1111111111111p-7, 0x1.1111111111111p-63},
+        {-0x1.a01a01a01a01ap-13, -0x1.a01a01a01a01ap-73},
+        {0x1.71de3a556c734p-19, -0x1.c154f8ddc6c00p-73},
+        {-0x1.ae64567f544e4p-26, 0x1.c062e06d1f209p-80},
+        {0x1.6124613a86d09p-33, 0x1.f28e0cc748ebep-87},
+        {-0x1.ae7f3e733b81fp-41, -0x1.1d8656b0ee8cbp-97},
+        {0x1.952c77030ad4ap-49, 0x1.ac981465ddc6cp-103},
+        {-0x1.2f49b46814157p-57, -0x1.2650f61dbdcb4p-112},
+        {0x1.71b8ef6dcf572p-66, -0x1.d043ae40c4647p-120},
+        {-0x1.761b41316381ap-75, 0x1.3423c7d91404fp-130},
+        {0x1.3f3ccdd165fa9p-84, -0x1.58ddadf344487p-139},
+        {-0x1.d1ab1c2dccea3p-94, -0x1.054d0c78aea14p-149}};
+    const double C[15][2] = {
+        {0x1.0000000000000p+0, 0x0.0p+0},
+        {-0x1.0000000000000p-1, 0x0.0p+0},
+        {0x1.5555555555555p-5, 0x1.5555555555555p-59},
+        {-0x1.6c16c16c16c17p-10, 0x1.f49f49f49f49fp-65},
+        {0x1.a01a01a01a01ap-16, 0x1.a01a01a01a01ap-76},
+        {-0x1.27e4fb7789f5cp-22, -0x1.cbbc05b4fa99ap-76},
+        {0x1.1eed8eff8d898p-29, -0x1.2aec959e14c06p-83},
+        {-0x1.93974a8c07c9dp-37, -0x1.05d6f8a2efd1fp-92},
+        {0x1.ae7f3e733b81fp-45, 0x1.1d8656b0ee8cbp-101},
+        {-0x1.6827863b97d97p-53, -0x1.eec01221a8b0bp-107},
+        {0x1.e542ba4020225p-62, 0x1.ea72b4afe3c2fp-120},
+        {-0x1.0ce396db7f853p-70, 0x1.aebcdbd20331cp-124},
+        {0x1.f2cf01972f578p-80, -0x1.9ada5fcc1ab14p-135},
+        {-0x1.88e85fc6a4e5ap-89, 0x1.71c37ebd16540p-143},
+        {0x1.0a18a2635085dp-98, 0x1.b9e2e28e1aa54p-153}};
+    dd ps = dd{S[13][0], S[13][1]};
+    for (int j = 12; j >= 0; j--) ps = dd_add(dd_mul(ps, r2), dd{S[j][0], S[j][1]});
+    dd pc = dd{C[14][0], C[14][1]};
+    for (int j = 13; j >= 0; j--) pc = dd_add(dd_mul(pc, r2), dd{C[j][0], C[j][1]});
+    const dd sr = dd_mul(ps, r);
+    const double sv = sr.hi + sr.lo, cv = pc.hi + pc.lo;
+    const int q = ((int)k) & 3;
+    s_out = q == 0 ? sv : (q == 1 ? cv : (q == 2 ? -sv : -cv));
+    c_out = q == 0 ? cv : (q == 1 ? -sv : (q == 2 ? -cv : sv));
+}
+}  // namespace cray

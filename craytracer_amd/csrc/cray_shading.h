@@ -96,14 +96,18 @@ __device__ __forceinline__ void sample_disk(double u, double v, double& x, doubl
     double r, theta;
     if (fabs(u) > fabs(v)) { r = u; theta = kQuarterPi * v / u; }
     else { r = v; theta = kHalfPi - kQuarterPi * u / v; }
-    x = cos(theta) * r;
-    y = sin(theta) * r;
+    double st, ct;
+    sincos_cr(theta, st, ct);  // correctly rounded, see cray_math.h
+    x = ct * r;
+    y = st * r;
 }
 __device__ __forceinline__ vec3 sample_sphere(double u, double v) {
     double z = 1.0 - 2.0 * u;
     double r = sqrt(max_nn(1.0 - square(z), 0.0));
     double phi = 2.0 * kPi * v;
-    return mk(r * cos(phi), r * sin(phi), z);
+    double sp, cp;
+    sincos_cr(phi, sp, cp);
+    return mk(r * cp, r * sp, z);
 }
 __device__ __forceinline__ vec3 cosine_hemisphere(double u, double v, vec3 n) {
     vec3 t, b;

@@ -34,6 +34,10 @@ const cray_flat_scene* cray_host_scene_flat(const cray_host_scene* scene);
 double cray_host_scene_build_seconds(const cray_host_scene* scene);
 void cray_host_scene_free(cray_host_scene* scene);
 
+/* The correctly rounded sin/cos the kernels use in sample_disk / sample_sphere
+ * (src/sampling.rs:17-39), evaluated on the host by the very same code (cray_math.h). */
+void cray_host_sincos(double x, double* sin_out, double* cos_out);
+
 #ifdef __cplusplus
 }
 #endif

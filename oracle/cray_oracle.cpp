@@ -19,6 +19,8 @@
  *    therefore "oracle == product", conditional on that table for "== real binary".
  *  - The reference binary itself cannot be built here (no rustc/cargo).
  */
+#include <quadmath.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -183,6 +185,21 @@ struct Sampler {
 };
 
 /* ======================================================================== */
+/* sin / cos of the sampling functions                                        */
+/* ======================================================================== */
+/* Rust documents f64::sin/cos as platform-precision ("The precision of this function is
+ * non-deterministic", std docs): on Linux they are glibc's, which round ~0.15 % of calls the
+ * "wrong" way and differ in the last bit from any other libm.  The reference's shadow-ray
+ * leak (scenes/rounding-error.cry) amplifies such a 1-ulp difference into a different path
+ * about once per 3000 paths, so "identical results" needs ONE definite sin/cos.  The oracle
+ * uses the canonical one: the correctly rounded value, obtained through binary128
+ * (libquadmath).  g_libm_mode = 1 switches to the platform libm to measure the difference
+ * (tests/test_oracle_libm.py). */
+static int g_libm_mode = 0;
+static inline double sample_sin(double x) { return g_libm_mode ? std::sin(x) : (double)sinq((__float128)x); }
+static inline double sample_cos(double x) { return g_libm_mode ? std::cos(x) : (double)cosq((__float128)x); }
+
+/* ======================================================================== */
 /* sampling_fns, src/sampling.rs:1-66                                         */
 /* ======================================================================== */
 static inline double power_heuristic(double pdf_f, double pdf_g) { /* :11-15 with n_f = n_g = 1 */
@@ -195,14 +212,14 @@ static inline void sample_disk(double u, double v, double* x, double* y) { /* :1
     double r, theta;
     if (std::fabs(u) > std::fabs(v)) { r = u; theta = FRAC_PI_4 * v / u; }
     else { r = v; theta = FRAC_PI_2 - FRAC_PI_4 * u / v; }
-    *x = std::cos(theta) * r;
-    *y = std::sin(theta) * r;
+    *x = sample_cos(theta) * r;
+    *y = sample_sin(theta) * r;
 }
 static inline V3 sample_sphere(double u, double v) { /* :31-39 */
     double z = 1.0 - 2.0 * u;
     double r = std::sqrt(rmax(1.0 - sq(z), 0.0));
     double phi = 2.0 * PI * v;
-    return v3(r * std::cos(phi), r * std::sin(phi), z);
+    return v3(r * sample_cos(phi), r * sample_sin(phi), z);
 }
 static inline V3 sample_hemisphere(double u, double v, V3 normal) { /* :41-48 */
     V3 r = sample_sphere(u, v);
@@ -1497,6 +1514,11 @@ void orc_camera_ray(void* s, uint64_t seed, uint32_t x, uint32_t y, uint32_t sam
     Ray r = camera_sample(*sc, fx, fy, lx, ly, x, y);
     ray7[0] = r.o.x; ray7[1] = r.o.y; ray7[2] = r.o.z; ray7[3] = r.d.x; ray7[4] = r.d.y; ray7[5] = r.d.z; ray7[6] = r.tmax;
 }
+
+/* 0: correctly rounded sin/cos in the sampling functions (default); 1: platform libm */
+void orc_set_libm_mode(int mode) { g_libm_mode = mode; }
+double orc_sample_sin(double x) { return sample_sin(x); }
+double orc_sample_cos(double x) { return sample_cos(x); }
 
 /* ---- unit hooks for the reference's known-answer tests ------------------- */
 uint64_t orc_siphash(const uint8_t* msg, uint64_t len, uint64_t k0, uint64_t k1, int c, int d) {

@@ -85,9 +85,19 @@ def lib():
         L.orc_color_to_rgb.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_partition_by.restype = C.c_uint64
         L.orc_partition_by.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int64, C.c_int64]
+        L.orc_set_libm_mode.argtypes = [C.c_int]
+        L.orc_sample_sin.restype = C.c_double
+        L.orc_sample_sin.argtypes = [C.c_double]
+        L.orc_sample_cos.restype = C.c_double
+        L.orc_sample_cos.argtypes = [C.c_double]
         L.orc_sampling_fn.argtypes = [C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
+
+
+def set_libm_mode(mode):
+    """0: correctly rounded sin/cos in the sampling functions (default); 1: platform libm."""
+    lib().orc_set_libm_mode(mode)
 
 
 def _f64(a):
