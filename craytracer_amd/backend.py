@@ -27,7 +27,7 @@ class RenderParams(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
-                ('paths', 'closest_rays', 'shadow_rays', 'closest_nodes', 'closest_prims', 'shadow_nodes',
+                ('paths', 'closest_rays', 'shadow_rays', 'shadow_skipped', 'closest_nodes', 'closest_prims', 'shadow_nodes',
                  'shadow_prims', 'closest_tri_tests', 'shadow_tri_tests', 'nonfinite', 'stack_overflow')] + \
                [(n, C.c_double) for n in ('seconds', 'trace_closest_ms', 'trace_any_ms', 'shade_ms', 'other_ms')] + \
                [(n, C.c_uint32) for n in ('trace_closest_launches', 'trace_any_launches', 'shade_launches', 'pad_')]

@@ -110,8 +110,8 @@ struct Counters {
     unsigned long long closest_rays, shadow_rays;
     unsigned long long closest_nodes, closest_prims, shadow_nodes, shadow_prims;
     unsigned long long closest_tri, shadow_tri;
-    unsigned long long nonfinite, stack_overflow;
-    unsigned int n_active[2], n_shadow, pad_;
+    unsigned long long nonfinite, stack_overflow, shadow_skipped;
+    unsigned int n_active[2], n_shadow, trace_head;
 };
 
 }  // namespace cray

@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -49,6 +50,8 @@ struct cray_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int n_cu = 256;
+    unsigned int refill_min = 40;  // idle lanes a wave waits for before it fetches new rays
+    int trace_blocks_per_cu = 4;
     // path-state pool
     size_t capacity = 0;
     std::vector<void*> state_allocs;
@@ -159,7 +162,7 @@ int grid_for(const cray_ctx* c, size_t n, int blocks_per_cu) {
 }
 
 void fill_stats(const Counters& h, cray_stats* st) {
-    st->closest_rays = h.closest_rays; st->shadow_rays = h.shadow_rays;
+    st->closest_rays = h.closest_rays; st->shadow_rays = h.shadow_rays + h.shadow_skipped; st->shadow_skipped = h.shadow_skipped;
     st->closest_nodes = h.closest_nodes; st->closest_prims = h.closest_prims;
     st->shadow_nodes = h.shadow_nodes; st->shadow_prims = h.shadow_prims;
     st->closest_tri_tests = h.closest_tri; st->shadow_tri_tests = h.shadow_tri;
@@ -188,6 +191,8 @@ extern "C" int cray_ctx_create(int device_id, void* stream, cray_ctx** out) {
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else { HIP_TRY(hipStreamCreate(&c->stream)); c->own_stream = true; }
     HIP_TRY(hipMalloc((void**)&c->counters, sizeof(Counters)));
+    if (const char* e = getenv("CRAY_REFILL_MIN")) c->refill_min = (unsigned int)atoi(e);
+    if (const char* e = getenv("CRAY_TRACE_BLOCKS_PER_CU")) c->trace_blocks_per_cu = atoi(e);
     *out = c;
     return CRAY_OK;
 }
@@ -396,24 +401,26 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
         uint32_t* q_next = c->queue[(b + 1) & 1];
         unsigned int* n_next = &ctr->n_active[(b + 1) & 1];
         // an upper bound of the live paths is not known on the host: size the grids for the pass
-        const int g_trace = grid_for(c, n_paths, 8);
+        const int g_trace = grid_for(c, n_paths, c->trace_blocks_per_cu);  // persistent: 4 blocks x 4 waves per CU at 4 waves/SIMD
         const int g_shade = grid_for(c, n_paths, 4);
 
+        HIP_TRY(hipMemsetAsync(&ctr->trace_head, 0, sizeof(unsigned int), st));
         if (tm) { int e = tm->begin(FAM_CLOSEST); if (e) return e; }
-        if (count) hipLaunchKernelGGL((k_trace<false, true>), dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, q, nq, n_paths, (const double*)nullptr, ctr);
-        else hipLaunchKernelGGL((k_trace<false, false>), dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, q, nq, n_paths, (const double*)nullptr, ctr);
+        if (count) hipLaunchKernelGGL((k_trace<false, true>), dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
+        else hipLaunchKernelGGL((k_trace<false, false>), dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
         if (tm) { int e = tm->end(); if (e) return e; }
 
         HIP_TRY(hipMemsetAsync(n_next, 0, sizeof(unsigned int), st));
         HIP_TRY(hipMemsetAsync(&ctr->n_shadow, 0, sizeof(unsigned int), st));
+        HIP_TRY(hipMemsetAsync(&ctr->trace_head, 0, sizeof(unsigned int), st));
         if (tm) { int e = tm->begin(FAM_SHADE); if (e) return e; }
         hipLaunchKernelGGL(k_shade, dim3(g_shade), dim3(kBlock), 0, st, d, c->ps, q, nq, n_paths, b, spp_pass, pp.s_lo, q_next, n_next,
-                           c->shadow_queue, &ctr->n_shadow, ctr);
+                           c->shadow_queue, &ctr->n_shadow, ctr, count ? 1u : 0u);
         if (tm) { int e = tm->end(); if (e) return e; }
 
         if (tm) { int e = tm->begin(FAM_ANY); if (e) return e; }
-        if (count) hipLaunchKernelGGL((k_trace<true, true>), dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, c->shadow_queue, &ctr->n_shadow, 0u, (const double*)nullptr, ctr);
-        else hipLaunchKernelGGL((k_trace<true, false>), dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, c->shadow_queue, &ctr->n_shadow, 0u, (const double*)nullptr, ctr);
+        if (count) hipLaunchKernelGGL((k_trace<true, true>), dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, c->shadow_queue, &ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
+        else hipLaunchKernelGGL((k_trace<true, false>), dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, c->shadow_queue, &ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
         if (tm) { int e = tm->end(); if (e) return e; }
     }
     if (tm) { int e = tm->begin(FAM_OTHER); if (e) return e; }
@@ -622,7 +629,7 @@ extern "C" int cray_trace(cray_ctx* c, cray_scene* s, const cray_ray* rays, size
     }
     const int g = grid_for(c, n, 8);
     if (any_hit) {
-        hipLaunchKernelGGL((k_trace<true, true>), dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)nullptr, (const unsigned int*)nullptr, (uint32_t)n, (const double*)nullptr, c->counters);
+        hipLaunchKernelGGL((k_trace<true, true>), dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)nullptr, (const unsigned int*)nullptr, (uint32_t)n, (const double*)nullptr, c->counters, &c->counters->trace_head, c->refill_min);
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipMemcpy(col.data(), ps.lr, n * 8, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < n; i++) {
@@ -632,7 +639,7 @@ extern "C" int cray_trace(cray_ctx* c, cray_scene* s, const cray_ray* rays, size
         }
     } else {
         // closest hit with caller-supplied tmax: rays whose tmax is finite go through the same kernel via stmax
-        hipLaunchKernelGGL((k_trace<false, true>), dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)nullptr, (const unsigned int*)nullptr, (uint32_t)n, (const double*)ps.stmax, c->counters);
+        hipLaunchKernelGGL((k_trace<false, true>), dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)nullptr, (const unsigned int*)nullptr, (uint32_t)n, (const double*)ps.stmax, c->counters, &c->counters->trace_head, c->refill_min);
         cray_hit* d_hits = nullptr;
         HIP_TRY(hipMalloc((void**)&d_hits, n * sizeof(cray_hit)));
         hipLaunchKernelGGL(k_hit_records, dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (uint32_t)n, d_hits);

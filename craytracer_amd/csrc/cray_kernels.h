@@ -50,51 +50,85 @@ __device__ __forceinline__ double child_key(const double* __restrict__ lo, const
     return inside ? -inf64() : key;
 }
 
-struct TraceResult {
-    double t, u, v;
-    int32_t prim;
-    bool occluded;
-};
-
+// ---------------------------------------------------------------------------------
+// Scene::intersect / Scene::intersects over a queue of paths — persistent wavefront tracer.
+//
+// Rays of one launch need between ~5 and several hundred node visits; with one ray per lane
+// for the lifetime of a wave the 64-wide VALU ran at 15-19 % lane utilisation (rocprofv3
+// SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU, profiles/r01_v1_*).  Here every lane is a small
+// state machine: a lane whose ray is finished pulls the next ray index from a device-wide
+// queue head (one atomic per wave, ballot + prefix), and each loop iteration performs at most
+// one interior-node step followed by at most one leaf step, so lanes re-converge every
+// iteration.  Results do not depend on which lane traces which ray.
+//
+//  ANY = false: ray = path segment (tmax = +inf); writes the hit record.
+//  ANY = true : ray = the path's shadow ray; adds the stored NEE term to L when unoccluded
+//               (path_integrator.rs:141-163).
+//  COUNT      : also count popped nodes / primitive tests exactly as the reference visits them.
+// ---------------------------------------------------------------------------------
 template <bool ANY, bool COUNT>
-__device__ __forceinline__ TraceResult traverse(const DevScene& sc, ray_t ray, unsigned long long& n_nodes, unsigned long long& n_prims,
-                                                unsigned long long& n_tri, unsigned int& overflow) {
-    TraceResult res;
-    res.t = 0.0; res.u = 0.0; res.v = 0.0; res.prim = -1; res.occluded = false;
+__global__ void __launch_bounds__(kBlock) k_trace(DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
+                                                  const unsigned int* __restrict__ n_ptr, uint32_t n_fixed,
+                                                  const double* __restrict__ closest_tmax, Counters* ctr, unsigned int* work_head, unsigned int refill_min) {
+    const uint32_t n = n_ptr ? *n_ptr : n_fixed;
+    const unsigned int lane = __lane_id();
+    unsigned long long n_nodes = 0, n_prims = 0, n_tri = 0;
+    unsigned int overflow = 0;
 
     uint32_t sref[kStackDepth];
     double skey[kStackDepth];
     int sp = 0;
-
-    if (COUNT) n_nodes += 1;
-    if (!(child_key(sc.root_lo, sc.root_hi, ray.o, ray.d) < ray.tmax)) return res;
-    uint32_t cur = sc.root_ref;
+    bool active = false, exhausted = false;
+    uint32_t p = 0, cur = 0;
+    ray_t ray = mkray(mk(0, 0, 0), mk(0, 0, 1));
+    double hit_t = 0.0, hit_u = 0.0, hit_v = 0.0;
+    int32_t hit_prim = -1;
 
     for (;;) {
-        if (ref_is_leaf(cur)) {
-            const uint32_t first = ref_leaf_first(cur), count = ref_leaf_count(cur);
-            for (uint32_t k = 0; k < count; k++) {
-                const LeafSlot& s = sc.slots[first + k];
-                if (COUNT) n_prims += 1;
-                if (s.kind == CRAY_SHAPE_TRIANGLE) {
-                    if (COUNT) n_tri += 1;
-                    double t, u, v;
-                    if (tri_test(mk(s.v0[0], s.v0[1], s.v0[2]), mk(s.e1[0], s.e1[1], s.e1[2]), mk(s.e2[0], s.e2[1], s.e2[2]), ray, t, u, v)) {
-                        if (ANY) { res.occluded = true; return res; }
-                        ray.tmax = t;  // Ray::update_max_distance
-                        res.t = t; res.u = u; res.v = v; res.prim = (int32_t)s.prim;
-                    }
+        // ---- idle lanes fetch the next rays of the queue
+        const unsigned long long idle = __ballot(!active);
+        if ((unsigned int)__popcll(idle) >= refill_min && !exhausted) {
+            const unsigned int leader = __ffsll((long long)idle) - 1;
+            const unsigned int want = (unsigned int)__popcll(idle);
+            unsigned int base = 0;
+            if (lane == leader) base = atomicAdd(work_head, want);
+            base = __shfl(base, leader);
+            if (base + want >= n) exhausted = true;  // wave-uniform
+            const unsigned int mine = base + (unsigned int)__popcll(idle & ((1ull << lane) - 1ull));
+            if (!active && mine < n) {
+                p = queue ? queue[mine] : mine;
+                if (ANY) {
+                    ray.o = mk(ps.sox[p], ps.soy[p], ps.soz[p]);
+                    ray.d = mk(ps.sdx[p], ps.sdy[p], ps.sdz[p]);
+                    ray.tmax = ps.stmax[p];
                 } else {
-                    const cray_prim& pr = sc.prims[s.prim];
-                    bool hit = s.kind == CRAY_SHAPE_SPHERE ? sphere_hit(sc.spheres[pr.shape], ray, ANY, nullptr)
-                                                           : disk_hit(sc.disks[pr.shape], ray, ANY, nullptr);
-                    if (hit) {
-                        if (ANY) { res.occluded = true; return res; }
-                        res.t = ray.tmax; res.prim = (int32_t)s.prim;  // distance: ray.max_distance (primitive.rs:66)
-                    }
+                    ray.o = mk(ps.ox[p], ps.oy[p], ps.oz[p]);
+                    ray.d = mk(ps.dx[p], ps.dy[p], ps.dz[p]);
+                    ray.tmax = closest_tmax ? closest_tmax[p] : inf64();  // path segments are Ray::new -> +inf
+                }
+                hit_t = 0.0; hit_u = 0.0; hit_v = 0.0; hit_prim = -1;
+                sp = 0;
+                if (COUNT) n_nodes += 1;
+                if (child_key(sc.root_lo, sc.root_hi, ray.o, ray.d) < ray.tmax) {
+                    cur = sc.root_ref;
+                    active = true;
+                } else if (ANY) {  // root rejected: unoccluded
+                    ps.lr[p] = ps.lr[p] + ps.cr[p];
+                    ps.lg[p] = ps.lg[p] + ps.cg[p];
+                    ps.lb[p] = ps.lb[p] + ps.cb[p];
+                } else {
+                    ps.ht[p] = 0.0; ps.hu[p] = 0.0; ps.hv[p] = 0.0; ps.hprim[p] = -1;
                 }
             }
-        } else {
+        }
+        if (!__any(active)) {
+            if (exhausted) break;
+            continue;
+        }
+
+        bool need_pop = false, finished = false, occluded = false;
+        // ---- at most one interior step per iteration
+        if (active && !ref_is_leaf(cur)) {
             const InnerNode& nd = sc.inner[cur];
             const double k0 = child_key(nd.lo0, nd.hi0, ray.o, ray.d);
             const double k1 = child_key(nd.lo1, nd.hi1, ray.o, ray.d);
@@ -108,69 +142,71 @@ __device__ __forceinline__ TraceResult traverse(const DevScene& sc, ray_t ray, u
                 // count pops in the reference's order: near now, far when (if) it is popped
                 n_nodes += 1;
                 if (sp < kStackDepth) { sref[sp] = far; skey[sp] = kf; sp++; } else overflow = 1;
-                if (an) { cur = near; continue; }
-            } else {
-                if (an) {
-                    if (af) {
-                        if (sp < kStackDepth) { sref[sp] = far; skey[sp] = kf; sp++; } else overflow = 1;
-                    }
-                    cur = near;
-                    continue;
+                if (an) cur = near; else need_pop = true;
+            } else if (an) {
+                if (af) {
+                    if (sp < kStackDepth) { sref[sp] = far; skey[sp] = kf; sp++; } else overflow = 1;
                 }
-                if (af) { cur = far; continue; }
+                cur = near;
+            } else if (af) {
+                cur = far;
+            } else {
+                need_pop = true;
             }
         }
-        // pop; a deferred child is re-tested against the current ray.tmax
-        for (;;) {
-            if (sp == 0) return res;
-            --sp;
-            if (COUNT && ANY) n_nodes += 1;
-            if (skey[sp] < ray.tmax) break;
-        }
-        cur = sref[sp];
-    }
-}
-
-// Scene::intersect / Scene::intersects over a queue of paths.
-//  ANY = false: ray = path segment (tmax = +inf); writes the hit record.
-//  ANY = true : ray = the path's shadow ray; adds the stored NEE term to L when unoccluded
-//               (path_integrator.rs:141-163).
-template <bool ANY, bool COUNT>
-__global__ void __launch_bounds__(kBlock) k_trace(DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
-                                                  const unsigned int* __restrict__ n_ptr, uint32_t n_fixed,
-                                                  const double* __restrict__ closest_tmax, Counters* ctr) {
-    const uint32_t n = n_ptr ? *n_ptr : n_fixed;
-    unsigned long long nodes = 0, prims = 0, tris = 0;
-    unsigned int overflow = 0;
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint32_t p = queue ? queue[i] : i;
-        ray_t ray;
-        if (ANY) {
-            ray.o = mk(ps.sox[p], ps.soy[p], ps.soz[p]);
-            ray.d = mk(ps.sdx[p], ps.sdy[p], ps.sdz[p]);
-            ray.tmax = ps.stmax[p];
-        } else {
-            ray.o = mk(ps.ox[p], ps.oy[p], ps.oz[p]);
-            ray.d = mk(ps.dx[p], ps.dy[p], ps.dz[p]);
-            ray.tmax = closest_tmax ? closest_tmax[p] : inf64();  // path segments are Ray::new -> +inf
-        }
-        TraceResult r = traverse<ANY, COUNT>(sc, ray, nodes, prims, tris, overflow);
-        if (ANY) {
-            if (!r.occluded) {
-                ps.lr[p] = ps.lr[p] + ps.cr[p];
-                ps.lg[p] = ps.lg[p] + ps.cg[p];
-                ps.lb[p] = ps.lb[p] + ps.cb[p];
+        // ---- then at most one leaf step (including leaves reached just above)
+        if (active && !need_pop && ref_is_leaf(cur)) {
+            const uint32_t first = ref_leaf_first(cur), count = ref_leaf_count(cur);
+            for (uint32_t k = 0; k < count; k++) {
+                const LeafSlot& s = sc.slots[first + k];
+                if (COUNT) n_prims += 1;
+                if (s.kind == CRAY_SHAPE_TRIANGLE) {
+                    if (COUNT) n_tri += 1;
+                    double t, u, v;
+                    if (tri_test(mk(s.v0[0], s.v0[1], s.v0[2]), mk(s.e1[0], s.e1[1], s.e1[2]), mk(s.e2[0], s.e2[1], s.e2[2]), ray, t, u, v)) {
+                        if (ANY) { occluded = true; break; }
+                        ray.tmax = t;  // Ray::update_max_distance
+                        hit_t = t; hit_u = u; hit_v = v; hit_prim = (int32_t)s.prim;
+                    }
+                } else {
+                    const cray_prim& pr = sc.prims[s.prim];
+                    bool hit = s.kind == CRAY_SHAPE_SPHERE ? sphere_hit(sc.spheres[pr.shape], ray, ANY, nullptr)
+                                                           : disk_hit(sc.disks[pr.shape], ray, ANY, nullptr);
+                    if (hit) {
+                        if (ANY) { occluded = true; break; }
+                        hit_t = ray.tmax; hit_prim = (int32_t)s.prim;  // distance: ray.max_distance (primitive.rs:66)
+                    }
+                }
             }
-        } else {
-            ps.ht[p] = r.t; ps.hu[p] = r.u; ps.hv[p] = r.v; ps.hprim[p] = r.prim;
+            if (ANY && occluded) finished = true; else need_pop = true;
+        }
+        // ---- pop: a deferred child is re-tested against the current (shrunken) ray.tmax
+        if (active && need_pop) {
+            for (;;) {
+                if (sp == 0) { finished = true; break; }
+                --sp;
+                if (COUNT && ANY) n_nodes += 1;
+                if (skey[sp] < ray.tmax) { cur = sref[sp]; break; }
+            }
+        }
+        if (active && finished) {
+            if (ANY) {
+                if (!occluded) {
+                    ps.lr[p] = ps.lr[p] + ps.cr[p];
+                    ps.lg[p] = ps.lg[p] + ps.cg[p];
+                    ps.lb[p] = ps.lb[p] + ps.cb[p];
+                }
+            } else {
+                ps.ht[p] = hit_t; ps.hu[p] = hit_u; ps.hv[p] = hit_v; ps.hprim[p] = hit_prim;
+            }
+            active = false;
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ANY ? &ctr->shadow_rays : &ctr->closest_rays, (unsigned long long)n);
     if (COUNT) {
-        if (nodes) atomicAdd(ANY ? &ctr->shadow_nodes : &ctr->closest_nodes, nodes);
-        if (prims) atomicAdd(ANY ? &ctr->shadow_prims : &ctr->closest_prims, prims);
-        if (tris) atomicAdd(ANY ? &ctr->shadow_tri : &ctr->closest_tri, tris);
+        if (n_nodes) atomicAdd(ANY ? &ctr->shadow_nodes : &ctr->closest_nodes, n_nodes);
+        if (n_prims) atomicAdd(ANY ? &ctr->shadow_prims : &ctr->closest_prims, n_prims);
+        if (n_tri) atomicAdd(ANY ? &ctr->shadow_tri : &ctr->closest_tri, n_tri);
     }
     if (overflow) atomicAdd(&ctr->stack_overflow, 1ull);
 }
@@ -215,12 +251,12 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, PathState ps, con
                                                   const unsigned int* __restrict__ n_ptr, uint32_t n_fixed, uint32_t bounce,
                                                   uint32_t spp_pass, uint32_t s_lo, uint32_t* __restrict__ next_queue,
                                                   unsigned int* next_count, uint32_t* __restrict__ shadow_queue,
-                                                  unsigned int* shadow_count, Counters* ctr) {
+                                                  unsigned int* shadow_count, Counters* ctr, uint32_t trace_all_shadow) {
     const uint32_t n = n_ptr ? *n_ptr : n_fixed;
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t n_round = (n + 63u) & ~63u;  // keep whole waves in the loop for the ballots
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
-        bool want_shadow = false, want_next = false;
+        bool want_shadow = false, want_next = false, skip_shadow = false;
         uint32_t p = 0;
         if (i < n) {
             p = queue ? queue[i] : i;
@@ -327,7 +363,11 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, PathState ps, con
                     ps.sdx[p] = w_i.x; ps.sdy[p] = w_i.y; ps.sdz[p] = w_i.z;
                     ps.stmax[p] = s_tmax;
                     ps.cr[p] = contrib.r; ps.cg[p] = contrib.g; ps.cb[p] = contrib.b;
-                    want_shadow = true;  // the reference queries Scene::intersects unconditionally (:141)
+                    // The reference queries Scene::intersects unconditionally (:141).  When the term it
+                    // gates is exactly zero (purely specular lobes, pdf 0, black f) the answer cannot
+                    // change L (L + 0 == L), so the query is skipped unless traversal is being counted.
+                    want_shadow = trace_all_shadow || !black(contrib);
+                    skip_shadow = !want_shadow;
                 }
 
                 // BSDF sample, throughput update, roulette (:167-206)
@@ -368,6 +408,10 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, PathState ps, con
             }
         }
         queue_push(shadow_queue, shadow_count, want_shadow, p);
+        {
+            const unsigned long long sk = __ballot(skip_shadow);
+            if (sk != 0 && __lane_id() == (unsigned int)(__ffsll((long long)sk) - 1)) atomicAdd(&ctr->shadow_skipped, (unsigned long long)__popcll(sk));
+        }
         queue_push(next_queue, next_count, want_next, p);
     }
 }

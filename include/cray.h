@@ -105,7 +105,10 @@ typedef struct {
 
 typedef struct {
     uint64_t paths;                         /* W*H*spp rendered by this call */
-    uint64_t closest_rays, shadow_rays;     /* Scene::intersect / Scene::intersects calls */
+    uint64_t closest_rays, shadow_rays;     /* Scene::intersect / Scene::intersects calls the reference makes */
+    uint64_t shadow_skipped;                /* of shadow_rays: not traversed because the NEE term they gate is
+                                               exactly (0,0,0) (e.g. any hit on a purely specular material);
+                                               always 0 when count_traversal is set */
     uint64_t closest_nodes, closest_prims;  /* nodes popped / primitives tested (count_traversal) */
     uint64_t shadow_nodes, shadow_prims;
     uint64_t closest_tri_tests, shadow_tri_tests;
