@@ -18,6 +18,10 @@ namespace cray {
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kNoRef = 0xffffffffu;
 constexpr int kStackDepth = 96;
+#ifndef CRAY_LDS_STACK
+#define CRAY_LDS_STACK 12
+#endif
+constexpr int kLdsStack = CRAY_LDS_STACK;  // entries per lane kept in LDS (12 B each)
 
 // child reference: interior -> index into DevScene::inner;
 // leaf -> kLeafBit | first_slot << 3 | (count - 1), count in 1..8

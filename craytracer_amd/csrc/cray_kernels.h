@@ -66,8 +66,11 @@ __device__ __forceinline__ double child_key(const double* __restrict__ lo, const
 //               (path_integrator.rs:141-163).
 //  COUNT      : also count popped nodes / primitive tests exactly as the reference visits them.
 // ---------------------------------------------------------------------------------
+#ifndef CRAY_TRACE_WAVES
+#define CRAY_TRACE_WAVES 4
+#endif
 template <bool ANY, bool COUNT>
-__global__ void __launch_bounds__(kBlock) k_trace(DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
+__global__ void __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace(DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
                                                   const unsigned int* __restrict__ n_ptr, uint32_t n_fixed,
                                                   const double* __restrict__ closest_tmax, Counters* ctr, unsigned int* work_head, unsigned int refill_min) {
     const uint32_t n = n_ptr ? *n_ptr : n_fixed;
@@ -75,8 +78,19 @@ __global__ void __launch_bounds__(kBlock) k_trace(DevScene sc, PathState ps, con
     unsigned long long n_nodes = 0, n_prims = 0, n_tri = 0;
     unsigned int overflow = 0;
 
-    uint32_t sref[kStackDepth];
-    double skey[kStackDepth];
+    // Traversal stack: the bottom kLdsStack entries of every lane live in LDS ([entry][thread], so a
+    // wave's access is conflict-free), deeper entries (rare) spill to scratch.
+    __shared__ uint32_t lds_ref[kLdsStack * kBlock];
+    __shared__ double lds_key[kLdsStack * kBlock];
+    uint32_t sref[kStackDepth - kLdsStack];
+    double skey[kStackDepth - kLdsStack];
+    const unsigned int tid = threadIdx.x;
+#define CRAY_PUSH(r_, k_)                                                                  \
+    do {                                                                                   \
+        if (sp < kLdsStack) { lds_ref[sp * kBlock + tid] = (r_); lds_key[sp * kBlock + tid] = (k_); sp++; } \
+        else if (sp < kStackDepth) { sref[sp - kLdsStack] = (r_); skey[sp - kLdsStack] = (k_); sp++; }      \
+        else overflow = 1;                                                                 \
+    } while (0)
     int sp = 0;
     bool active = false, exhausted = false;
     uint32_t p = 0, cur = 0;
@@ -141,12 +155,10 @@ __global__ void __launch_bounds__(kBlock) k_trace(DevScene sc, PathState ps, con
             if (COUNT && ANY) {
                 // count pops in the reference's order: near now, far when (if) it is popped
                 n_nodes += 1;
-                if (sp < kStackDepth) { sref[sp] = far; skey[sp] = kf; sp++; } else overflow = 1;
+                CRAY_PUSH(far, kf);
                 if (an) cur = near; else need_pop = true;
             } else if (an) {
-                if (af) {
-                    if (sp < kStackDepth) { sref[sp] = far; skey[sp] = kf; sp++; } else overflow = 1;
-                }
+                if (af) CRAY_PUSH(far, kf);
                 cur = near;
             } else if (af) {
                 cur = far;
@@ -186,7 +198,8 @@ __global__ void __launch_bounds__(kBlock) k_trace(DevScene sc, PathState ps, con
                 if (sp == 0) { finished = true; break; }
                 --sp;
                 if (COUNT && ANY) n_nodes += 1;
-                if (skey[sp] < ray.tmax) { cur = sref[sp]; break; }
+                const double key = sp < kLdsStack ? lds_key[sp * kBlock + tid] : skey[sp - kLdsStack];
+                if (key < ray.tmax) { cur = sp < kLdsStack ? lds_ref[sp * kBlock + tid] : sref[sp - kLdsStack]; break; }
             }
         }
         if (active && finished) {
@@ -209,6 +222,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(DevScene sc, PathState ps, con
         if (n_tri) atomicAdd(ANY ? &ctr->shadow_tri : &ctr->closest_tri, n_tri);
     }
     if (overflow) atomicAdd(&ctr->stack_overflow, 1ull);
+#undef CRAY_PUSH
 }
 
 // render_pixel up to the camera ray (craytracer.rs:148-156) for every path of a pass.
@@ -247,7 +261,10 @@ __device__ __forceinline__ void queue_push(uint32_t* __restrict__ q, unsigned in
 }
 
 // The body of one estimate_Li iteration between the two BVH queries (path_integrator.rs:56-211).
-__global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
+#ifndef CRAY_SHADE_WAVES
+#define CRAY_SHADE_WAVES 1
+#endif
+__global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
                                                   const unsigned int* __restrict__ n_ptr, uint32_t n_fixed, uint32_t bounce,
                                                   uint32_t spp_pass, uint32_t s_lo, uint32_t* __restrict__ next_queue,
                                                   unsigned int* next_count, uint32_t* __restrict__ shadow_queue,

@@ -97,7 +97,11 @@ __device__ __forceinline__ void sample_disk(double u, double v, double& x, doubl
     if (fabs(u) > fabs(v)) { r = u; theta = kQuarterPi * v / u; }
     else { r = v; theta = kHalfPi - kQuarterPi * u / v; }
     double st, ct;
+#ifdef CRAY_EXPERIMENT_OCML_TRIG
+    st = sin(theta); ct = cos(theta);
+#else
     sincos_cr(theta, st, ct);  // correctly rounded, see cray_math.h
+#endif
     x = ct * r;
     y = st * r;
 }
