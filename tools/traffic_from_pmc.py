@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""profiles/hbm_traffic.json from a rocprofv3 `--pmc FETCH_SIZE` (and optionally WRITE_SIZE) pass.
+
+HBM bytes = FETCH_SIZE[KB] * 1024 * 2: on gfx950 FETCH_SIZE counts 128-B requests as 64 B
+(MI355X_MICROARCH.md "HBM"); tools/calib_fetch.hip confirms the factor for THIS access pattern
+(random whole 128-B records, 16 B per lane per load: 1.707 GB reported for 3.322 GB read; a
+coalesced 16-B/lane stream: 1.611 GB reported for 3.221 GB read).  WRITE_SIZE is taken as is.
+usage: traffic_from_pmc.py <workload> <fetch counter_collection.csv> [<write counter_collection.csv>]"""
+import json
+import os
+import sys
+
+import pandas as pd
+
+FETCH_CORRECTION = 2.0
+
+
+def per_kernel(csv, counter):
+    df = pd.read_csv(csv)
+    df = df[df['Counter_Name'] == counter]
+    df['k'] = df['Kernel_Name'].str.extract(r'(k_\w+(?:<\w+, \w+>)?)')
+    g = df.groupby('k')['Counter_Value']
+    return g.sum().to_dict(), g.count().to_dict()
+
+
+if __name__ == '__main__':
+    workload, fetch_csv = sys.argv[1], sys.argv[2]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, 'profiles', 'hbm_traffic.json')
+    data = json.load(open(path)) if os.path.exists(path) else {}
+    fs, fc = per_kernel(fetch_csv, 'FETCH_SIZE')
+    entry = {'source': os.path.relpath(fetch_csv, root), 'fetch_correction': FETCH_CORRECTION, 'kernels': {}}
+    for k in fs:
+        entry['kernels'][k] = {'launches': int(fc[k]), 'fetch_bytes_per_launch': fs[k] * 1024 * FETCH_CORRECTION / fc[k]}
+    if len(sys.argv) > 3:
+        ws, wc = per_kernel(sys.argv[3], 'WRITE_SIZE')
+        for k in ws:
+            entry['kernels'].setdefault(k, {})['write_bytes_per_launch'] = ws[k] * 1024 / wc[k]
+    kc = entry['kernels'].get('k_trace<false, false>', {})
+    entry['trace_closest_bytes_per_launch'] = round(kc.get('fetch_bytes_per_launch', 0) + kc.get('write_bytes_per_launch', 0))
+    data[workload] = entry
+    json.dump(data, open(path, 'w'), indent=1)
+    print(json.dumps(entry, indent=1))
