@@ -1,0 +1,59 @@
+"""Command line of the MI355X backend: the reference's CLI (src/bin/craytracer.rs:321-334:
+--scene, --output, --seed) plus the film/spp/depth overrides every BASELINE config needs.
+
+    python -m craytracer_amd --scene scenes/simple.cry --output out.pfm --width 256 --height 256 --spp 16 --max-depth 4
+
+Output: PFM (linear f32 RGB, the un-tonemapped buffer the reference hands to its EXR writer,
+craytracer.rs:366-370) or .npy.  The EXR writer and the preview window are out of scope.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+
+def write_pfm(path, img):
+    h, w, _ = img.shape
+    with open(path, 'wb') as f:
+        f.write(b'PF\n%d %d\n-1.0\n' % (w, h))
+        f.write(np.ascontiguousarray(img[::-1], dtype='<f4').tobytes())   # PFM rows go bottom to top
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog='craytracer_amd')
+    ap.add_argument('--scene', '-s', required=True)
+    ap.add_argument('--output', default='out.pfm')
+    ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--width', type=int, default=0)
+    ap.add_argument('--height', type=int, default=0)
+    ap.add_argument('--spp', type=int, default=0)
+    ap.add_argument('--max-depth', type=int, default=0)
+    ap.add_argument('--device', type=int, default=0)
+    args = ap.parse_args(argv)
+
+    from . import backend, cry
+    start = time.time()
+    try:
+        scene = cry.load_scene_file(args.scene, base_dir=os.getcwd(), width=args.width, height=args.height,
+                                    num_samples=args.spp, max_depth=args.max_depth)
+    except cry.ParserError as e:   # craytracer.rs:348-354
+        loc = '%s:%d:%d' % (args.scene, e.location[0], e.location[1]) if e.location else args.scene
+        print('%s %s %s' % (e.message, 'at' if e.location else 'in', loc), file=sys.stderr)
+        return 0
+    host = backend.HostScene(scene)
+    print('Scene constructed in %.1fs' % (time.time() - start), file=sys.stderr)
+    dev = backend.Context(args.device).upload(host)
+    film, st = dev.render(seed=args.seed)
+    print('Rendering finished in %.3fs (%.1f Mray/s)' % (st['seconds'], (st['closest_rays'] + st['shadow_rays'] - st['shadow_skipped']) / st['seconds'] / 1e6), file=sys.stderr)
+    if args.output.endswith('.npy'):
+        np.save(args.output, film)
+    else:
+        write_pfm(args.output, film)
+    print('Output written to %s' % args.output, file=sys.stderr)
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

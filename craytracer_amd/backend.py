@@ -68,7 +68,9 @@ class FlatScene(C.Structure):
 ABI_SYMBOLS = ['cray_ctx_create', 'cray_ctx_destroy', 'cray_scene_upload', 'cray_scene_free',
                'cray_scene_device_bytes', 'cray_render', 'cray_render_params_default', 'cray_render_samples',
                'cray_trace', 'cray_last_error', 'cray_host_scene_new', 'cray_host_scene_flat',
-               'cray_host_scene_build_seconds', 'cray_host_scene_free', 'cray_host_sincos']
+               'cray_host_scene_build_seconds', 'cray_host_scene_free', 'cray_host_sincos',
+               'cray_cry_tokenize', 'cray_cry_free_tokens', 'cray_cry_parse_value', 'cray_cry_free_string',
+               'cray_cry_parse_scene', 'cray_owned_scene_desc', 'cray_owned_scene_warnings', 'cray_owned_scene_free']
 
 _lib = None
 
