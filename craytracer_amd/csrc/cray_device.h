@@ -18,6 +18,7 @@ namespace cray {
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kNoRef = 0xffffffffu;
 constexpr int kStackDepth = 96;
+constexpr int kShadeClasses = 8;  // miss, area light, then material index (folded)
 #ifndef CRAY_LDS_STACK
 #define CRAY_LDS_STACK 12
 #endif
@@ -116,6 +117,7 @@ struct Counters {
     unsigned long long closest_tri, shadow_tri;
     unsigned long long nonfinite, stack_overflow, shadow_skipped;
     unsigned int n_active[2], n_shadow, trace_head;
+    unsigned int n_class[kShadeClasses];
 };
 
 }  // namespace cray

@@ -52,12 +52,15 @@ struct cray_ctx {
     int n_cu = 256;
     unsigned int refill_min = 40;  // idle lanes a wave waits for before it fetches new rays
     int trace_blocks_per_cu = 4;
+    int shade_blocks_per_cu = 4;
     // path-state pool
     size_t capacity = 0;
     std::vector<void*> state_allocs;
     PathState ps{};
     uint32_t* queue[2] = {nullptr, nullptr};
     uint32_t* shadow_queue = nullptr;
+    uint32_t* class_queues = nullptr;  // kShadeClasses x capacity (material sort)
+    int sort_shade = 0;
     Counters* counters = nullptr;
     uint32_t* pix_list = nullptr;
     size_t pix_capacity = 0;
@@ -116,6 +119,7 @@ int ensure_state(cray_ctx* c, size_t capacity) {
     if ((r = alloc(capacity * 4, (void**)&c->queue[0]))) return r;
     if ((r = alloc(capacity * 4, (void**)&c->queue[1]))) return r;
     if ((r = alloc(capacity * 4, (void**)&c->shadow_queue))) return r;
+    if (c->sort_shade && (r = alloc(capacity * 4 * kShadeClasses, (void**)&c->class_queues))) return r;
     c->capacity = capacity;
     return CRAY_OK;
 }
@@ -193,6 +197,8 @@ extern "C" int cray_ctx_create(int device_id, void* stream, cray_ctx** out) {
     HIP_TRY(hipMalloc((void**)&c->counters, sizeof(Counters)));
     if (const char* e = getenv("CRAY_REFILL_MIN")) c->refill_min = (unsigned int)atoi(e);
     if (const char* e = getenv("CRAY_TRACE_BLOCKS_PER_CU")) c->trace_blocks_per_cu = atoi(e);
+    if (const char* e = getenv("CRAY_SHADE_BLOCKS_PER_CU")) c->shade_blocks_per_cu = atoi(e);
+    if (const char* e = getenv("CRAY_SORT_SHADE")) c->sort_shade = atoi(e);
     *out = c;
     return CRAY_OK;
 }
@@ -402,7 +408,7 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
         unsigned int* n_next = &ctr->n_active[(b + 1) & 1];
         // an upper bound of the live paths is not known on the host: size the grids for the pass
         const int g_trace = grid_for(c, n_paths, c->trace_blocks_per_cu);  // persistent: 4 blocks x 4 waves per CU at 4 waves/SIMD
-        const int g_shade = grid_for(c, n_paths, 4);
+        const int g_shade = grid_for(c, n_paths, c->shade_blocks_per_cu);
 
         HIP_TRY(hipMemsetAsync(&ctr->trace_head, 0, sizeof(unsigned int), st));
         if (tm) { int e = tm->begin(FAM_CLOSEST); if (e) return e; }
@@ -413,9 +419,17 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
         HIP_TRY(hipMemsetAsync(n_next, 0, sizeof(unsigned int), st));
         HIP_TRY(hipMemsetAsync(&ctr->n_shadow, 0, sizeof(unsigned int), st));
         HIP_TRY(hipMemsetAsync(&ctr->trace_head, 0, sizeof(unsigned int), st));
+        if (c->sort_shade) HIP_TRY(hipMemsetAsync(ctr->n_class, 0, sizeof(unsigned int) * kShadeClasses, st));
         if (tm) { int e = tm->begin(FAM_SHADE); if (e) return e; }
-        hipLaunchKernelGGL(k_shade, dim3(g_shade), dim3(kBlock), 0, st, d, c->ps, q, nq, n_paths, b, spp_pass, pp.s_lo, q_next, n_next,
-                           c->shadow_queue, &ctr->n_shadow, ctr, count ? 1u : 0u);
+        if (c->sort_shade) {
+            hipLaunchKernelGGL(k_classify, dim3(grid_for(c, n_paths, 8)), dim3(kBlock), 0, st, d, c->ps, q, nq, n_paths, c->class_queues, c->capacity, ctr->n_class);
+            for (int cl = 0; cl < kShadeClasses; cl++)
+                hipLaunchKernelGGL(k_shade, dim3(g_shade), dim3(kBlock), 0, st, d, c->ps, (const uint32_t*)(c->class_queues + (size_t)cl * c->capacity),
+                                   (const unsigned int*)&ctr->n_class[cl], 0u, b, spp_pass, pp.s_lo, q_next, n_next, c->shadow_queue, &ctr->n_shadow, ctr, count ? 1u : 0u);
+        } else {
+            hipLaunchKernelGGL(k_shade, dim3(g_shade), dim3(kBlock), 0, st, d, c->ps, q, nq, n_paths, b, spp_pass, pp.s_lo, q_next, n_next,
+                               c->shadow_queue, &ctr->n_shadow, ctr, count ? 1u : 0u);
+        }
         if (tm) { int e = tm->end(); if (e) return e; }
 
         if (tm) { int e = tm->begin(FAM_ANY); if (e) return e; }

@@ -260,6 +260,36 @@ __device__ __forceinline__ void queue_push(uint32_t* __restrict__ q, unsigned in
     if (pred) q[base + __popcll(mask & ((1ull << lane) - 1ull))] = value;
 }
 
+// Material sort: split the live paths of a bounce into per-class queues (miss / emitter / material)
+// so that every k_shade launch runs one code path; a counting sort by wave ballots, one atomic per
+// wave and class.  MEASURED (profiles/r01_experiments.md): it makes k_shade 1.6-2x SLOWER on all three
+// configs (dragon 144 -> 234 ms, cornell 20.6 -> 41, staircase 640 -> 1326): shading is bound by
+// the path-state traffic (TCP pending-miss stalls, ~1000-cycle L2 read latency), and class queues
+// scatter the state accesses that the ascending compacted queue keeps nearly coalesced.  Kept
+// behind CRAY_SORT_SHADE=1 for later rounds (it only pays together with physical state compaction).
+__global__ void __launch_bounds__(kBlock) k_classify(DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
+                                                     const unsigned int* __restrict__ n_ptr, uint32_t n_fixed,
+                                                     uint32_t* __restrict__ class_queues, size_t class_stride, unsigned int* class_counts) {
+    const uint32_t n = n_ptr ? *n_ptr : n_fixed;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t n_round = (n + 63u) & ~63u;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+        int cls = -1;
+        uint32_t p = 0;
+        if (i < n) {
+            p = queue ? queue[i] : i;
+            const int32_t hp = ps.hprim[p];
+            if (hp < 0) cls = 0;
+            else {
+                const cray_prim pr = sc.prims[hp];
+                cls = pr.light >= 0 ? 1 : 2 + (pr.material % (kShadeClasses - 2));
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < kShadeClasses; c++) queue_push(class_queues + (size_t)c * class_stride, class_counts + c, cls == c, p);
+    }
+}
+
 // The body of one estimate_Li iteration between the two BVH queries (path_integrator.rs:56-211).
 #ifndef CRAY_SHADE_WAVES
 #define CRAY_SHADE_WAVES 1
@@ -330,6 +360,7 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
                 }
 
                 // next-event estimation (:129-164): build the shadow ray and the term it gates
+#ifndef CRAY_EXP_NO_NEE
                 {
                     double sel_pdf;
                     const uint32_t li = light_select(sc, sa[3], sel_pdf);
@@ -386,10 +417,16 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
                     want_shadow = trace_all_shadow || !black(contrib);
                     skip_shadow = !want_shadow;
                 }
+#endif
 
                 // BSDF sample, throughput update, roulette (:167-206)
                 LobeSample ls;
+#ifdef CRAY_EXP_NO_BSDF
+                ls.w_i = reflect(w_o, n_s); ls.f = mkc(1, 1, 1); ls.pdf = 1.0; ls.delta = true; ls.specular = true;
+                bool go = true;
+#else
                 bool go = material_sample(sc, mat, sa[0], sa[1], sa[2], w_o, n_s, sp.u, sp.v, ls);
+#endif
                 if (go && black(ls.f)) go = false;
                 double bsdf_pdf = 0.0;
                 if (go) {
