@@ -234,7 +234,8 @@ extern "C" int cray_scene_upload(cray_ctx* c, const cray_flat_scene* f, cray_sce
     HIP_TRY(hipSetDevice(c->device));
 
     // ---- leaf slots in leaf order; interior records with both children's bounds
-    std::vector<LeafSlot> slots(f->n_prim_refs);
+    std::vector<LeafSlot> slots((size_t)f->n_prim_refs + 1);  // +1: the unified 112-B record fetch of k_trace reads past an 80-B slot
+    memset(&slots[f->n_prim_refs], 0, sizeof(LeafSlot));
     for (uint32_t i = 0; i < f->n_prim_refs; i++) {
         uint32_t pi = f->prim_refs[i];
         if (pi >= f->n_prims) { set_last_error("prim_refs[%u] out of range", i); return CRAY_ERR_INVALID; }

@@ -141,14 +141,28 @@ __global__ void __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace(DevScene sc,
         }
 
         bool need_pop = false, finished = false, occluded = false;
-        // ---- at most one interior step per iteration
-        if (active && !ref_is_leaf(cur)) {
-            const InnerNode& nd = sc.inner[cur];
-            const double k0 = child_key(nd.lo0, nd.hi0, ray.o, ray.d);
-            const double k1 = child_key(nd.lo1, nd.hi1, ray.o, ray.d);
+        // ---- one record fetch per iteration: the interior node `cur` (7 x 16 B) or the first slot of
+        // the leaf `cur` (5 x 16 B) through the SAME seven load instructions, hence one memory wait per
+        // iteration for the whole wave instead of one for the node and a dependent one for the leaf.
+        const bool at_leaf = ref_is_leaf(cur);
+        double2 r0, r1, r2, r3, r4, r5, r6;
+        r0 = r1 = r2 = r3 = r4 = r5 = r6 = make_double2(0.0, 0.0);
+        if (active) {
+            const double2* rec = at_leaf ? reinterpret_cast<const double2*>(sc.slots + ref_leaf_first(cur))
+                                         : reinterpret_cast<const double2*>(sc.inner + cur);
+            r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3]; r4 = rec[4]; r5 = rec[5]; r6 = rec[6];
+        }
+        if (active && !at_leaf) {
+            const double lo0[3] = {r0.x, r0.y, r1.x}, hi0[3] = {r1.y, r2.x, r2.y};
+            const double lo1[3] = {r3.x, r3.y, r4.x}, hi1[3] = {r4.y, r5.x, r5.y};
+            const unsigned long long refs = (unsigned long long)__double_as_longlong(r6.x);
+            const uint32_t ref0 = (uint32_t)refs, ref1 = (uint32_t)(refs >> 32);
+            const uint32_t axis = (uint32_t)(unsigned long long)__double_as_longlong(r6.y);
+            const double k0 = child_key(lo0, hi0, ray.o, ray.d);
+            const double k1 = child_key(lo1, hi1, ray.o, ray.d);
             // bvh.rs:92-98: dir[axis] < 0 -> push left, push right => right is visited first
-            const bool right_first = comp(ray.d, (int)nd.axis) < 0.0;
-            const uint32_t near = right_first ? nd.ref1 : nd.ref0, far = right_first ? nd.ref0 : nd.ref1;
+            const bool right_first = comp(ray.d, (int)axis) < 0.0;
+            const uint32_t near = right_first ? ref1 : ref0, far = right_first ? ref0 : ref1;
             const double kn = right_first ? k1 : k0, kf = right_first ? k0 : k1;
             const bool an = kn < ray.tmax, af = kf < ray.tmax;
             if (COUNT && !ANY) n_nodes += 2;  // both children are popped and tested by the reference
@@ -165,28 +179,31 @@ __global__ void __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace(DevScene sc,
             } else {
                 need_pop = true;
             }
-        }
-        // ---- then at most one leaf step (including leaves reached just above)
-        if (active && !need_pop && ref_is_leaf(cur)) {
+        } else if (active) {
             const uint32_t first = ref_leaf_first(cur), count = ref_leaf_count(cur);
             for (uint32_t k = 0; k < count; k++) {
-                const LeafSlot& s = sc.slots[first + k];
+                if (k > 0) {  // further primitives of the leaf (13 % of the leaves hold 2, none more than 4)
+                    const double2* rec = reinterpret_cast<const double2*>(sc.slots + first + k);
+                    r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3]; r4 = rec[4];
+                }
+                const unsigned long long tag = (unsigned long long)__double_as_longlong(r4.y);
+                const uint32_t s_prim = (uint32_t)tag, s_kind = (uint32_t)(tag >> 32);
                 if (COUNT) n_prims += 1;
-                if (s.kind == CRAY_SHAPE_TRIANGLE) {
+                if (s_kind == CRAY_SHAPE_TRIANGLE) {
                     if (COUNT) n_tri += 1;
                     double t, u, v;
-                    if (tri_test(mk(s.v0[0], s.v0[1], s.v0[2]), mk(s.e1[0], s.e1[1], s.e1[2]), mk(s.e2[0], s.e2[1], s.e2[2]), ray, t, u, v)) {
+                    if (tri_test(mk(r0.x, r0.y, r1.x), mk(r1.y, r2.x, r2.y), mk(r3.x, r3.y, r4.x), ray, t, u, v)) {
                         if (ANY) { occluded = true; break; }
                         ray.tmax = t;  // Ray::update_max_distance
-                        hit_t = t; hit_u = u; hit_v = v; hit_prim = (int32_t)s.prim;
+                        hit_t = t; hit_u = u; hit_v = v; hit_prim = (int32_t)s_prim;
                     }
                 } else {
-                    const cray_prim& pr = sc.prims[s.prim];
-                    bool hit = s.kind == CRAY_SHAPE_SPHERE ? sphere_hit(sc.spheres[pr.shape], ray, ANY, nullptr)
-                                                           : disk_hit(sc.disks[pr.shape], ray, ANY, nullptr);
+                    const cray_prim& pr = sc.prims[s_prim];
+                    bool hit = s_kind == CRAY_SHAPE_SPHERE ? sphere_hit(sc.spheres[pr.shape], ray, ANY, nullptr)
+                                                         : disk_hit(sc.disks[pr.shape], ray, ANY, nullptr);
                     if (hit) {
                         if (ANY) { occluded = true; break; }
-                        hit_t = ray.tmax; hit_prim = (int32_t)s.prim;  // distance: ray.max_distance (primitive.rs:66)
+                        hit_t = ray.tmax; hit_prim = (int32_t)s_prim;  // distance: ray.max_distance (primitive.rs:66)
                     }
                 }
             }
