@@ -50,7 +50,7 @@ struct cray_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int n_cu = 256;
-    unsigned int refill_min = 40;  // idle lanes a wave waits for before it fetches new rays
+    unsigned int refill_min = 16;  // idle lanes a wave waits for before it fetches new rays
     int trace_blocks_per_cu = 4;
     int shade_blocks_per_cu = 4;
     // path-state pool

@@ -93,23 +93,34 @@ __global__ void __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace(DevScene sc,
     } while (0)
     int sp = 0;
     bool active = false, exhausted = false;
+    unsigned int res_base = 0, res_left = 0;  // wave-uniform reserve of queue positions
+    unsigned int chunk = n / (gridDim.x * (kBlock / 64) * 4u);
+    chunk = chunk < 64u ? 64u : (chunk > 512u ? 512u : chunk);
     uint32_t p = 0, cur = 0;
     ray_t ray = mkray(mk(0, 0, 0), mk(0, 0, 1));
     double hit_t = 0.0, hit_u = 0.0, hit_v = 0.0;
     int32_t hit_prim = -1;
 
     for (;;) {
-        // ---- idle lanes fetch the next rays of the queue
+        // ---- idle lanes fetch the next rays of the queue.  A wave reserves a chunk of consecutive queue
+        // positions with ONE atomic and hands them out over several refills, so that most refills do not
+        // start with a device-wide atomic round trip.
         const unsigned long long idle = __ballot(!active);
         if ((unsigned int)__popcll(idle) >= refill_min && !exhausted) {
-            const unsigned int leader = __ffsll((long long)idle) - 1;
-            const unsigned int want = (unsigned int)__popcll(idle);
-            unsigned int base = 0;
-            if (lane == leader) base = atomicAdd(work_head, want);
-            base = __shfl(base, leader);
-            if (base + want >= n) exhausted = true;  // wave-uniform
-            const unsigned int mine = base + (unsigned int)__popcll(idle & ((1ull << lane) - 1ull));
-            if (!active && mine < n) {
+            if (res_left == 0) {
+                const unsigned int leader = __ffsll((long long)idle) - 1;
+                unsigned int base = 0;
+                if (lane == leader) base = atomicAdd(work_head, chunk);
+                base = __shfl(base, leader);
+                if (base >= n) { exhausted = true; }
+                else { res_base = base; res_left = n - base < chunk ? n - base : chunk; }
+            }
+            const unsigned int rank = (unsigned int)__popcll(idle & ((1ull << lane) - 1ull));
+            const bool take = !active && rank < res_left;
+            const unsigned int mine = res_base + rank;
+            const unsigned int taken = (unsigned int)__popcll(__ballot(take));
+            res_base += taken; res_left -= taken;
+            if (take) {
                 p = queue ? queue[mine] : mine;
                 if (ANY) {
                     ray.o = mk(ps.sox[p], ps.soy[p], ps.soz[p]);
