@@ -18,7 +18,8 @@ namespace cray {
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kNoRef = 0xffffffffu;
 constexpr int kStackDepth = 96;
-constexpr int kShadeClasses = 8;  // miss, area light, then material index (folded)
+constexpr int kShadeClasses = 8;
+constexpr uint32_t kShadeTile = 2048;  // paths per block-level queue flush in k_shade (8 x 256)  // miss, area light, then material index (folded)
 #ifndef CRAY_LDS_STACK
 #define CRAY_LDS_STACK 12
 #endif

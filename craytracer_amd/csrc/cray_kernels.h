@@ -328,9 +328,18 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
                                                   unsigned int* next_count, uint32_t* __restrict__ shadow_queue,
                                                   unsigned int* shadow_count, Counters* ctr, uint32_t trace_all_shadow) {
     const uint32_t n = n_ptr ? *n_ptr : n_fixed;
-    const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t n_round = (n + 63u) & ~63u;  // keep whole waves in the loop for the ballots
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+    // Queue appends are aggregated per block over a tile of kShadeTile paths: survivors are collected
+    // in LDS (wave ballot + one LDS atomic per wave) and flushed with ONE global atomic per queue and
+    // tile.  One atomic per wave on a single device-wide counter (~88 returning atomics/us per word,
+    // MI355X_MICROARCH.md "dequeue") was half of this kernel's time: 1 M atomics per 33 M-path launch.
+    __shared__ uint32_t l_shadow[kShadeTile], l_next[kShadeTile];
+    __shared__ unsigned int c_shadow, c_next, c_skip, g_shadow, g_next;
+    const uint32_t n_tiles = (n + kShadeTile - 1) / kShadeTile;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+      if (threadIdx.x == 0) { c_shadow = 0; c_next = 0; c_skip = 0; }
+      __syncthreads();
+      for (uint32_t k = 0; k < kShadeTile / kBlock; k++) {
+        const uint32_t i = tile * kShadeTile + k * kBlock + threadIdx.x;
         bool want_shadow = false, want_next = false, skip_shadow = false;
         uint32_t p = 0;
         if (i < n) {
@@ -489,12 +498,23 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
                 }
             }
         }
-        queue_push(shadow_queue, shadow_count, want_shadow, p);
+        queue_push(l_shadow, &c_shadow, want_shadow, p);
+        queue_push(l_next, &c_next, want_next, p);
         {
             const unsigned long long sk = __ballot(skip_shadow);
-            if (sk != 0 && __lane_id() == (unsigned int)(__ffsll((long long)sk) - 1)) atomicAdd(&ctr->shadow_skipped, (unsigned long long)__popcll(sk));
+            if (sk != 0 && __lane_id() == (unsigned int)(__ffsll((long long)sk) - 1)) atomicAdd(&c_skip, (unsigned int)__popcll(sk));
         }
-        queue_push(next_queue, next_count, want_next, p);
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+          g_shadow = c_shadow ? atomicAdd(shadow_count, c_shadow) : 0u;
+          g_next = c_next ? atomicAdd(next_count, c_next) : 0u;
+          if (c_skip) atomicAdd(&ctr->shadow_skipped, (unsigned long long)c_skip);
+      }
+      __syncthreads();
+      for (uint32_t j = threadIdx.x; j < c_shadow; j += kBlock) shadow_queue[g_shadow + j] = l_shadow[j];
+      for (uint32_t j = threadIdx.x; j < c_next; j += kBlock) next_queue[g_next + j] = l_next[j];
+      __syncthreads();
     }
 }
 
