@@ -299,22 +299,35 @@ __global__ void __launch_bounds__(kBlock) k_classify(DevScene sc, PathState ps, 
                                                      const unsigned int* __restrict__ n_ptr, uint32_t n_fixed,
                                                      uint32_t* __restrict__ class_queues, size_t class_stride, unsigned int* class_counts) {
     const uint32_t n = n_ptr ? *n_ptr : n_fixed;
-    const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t n_round = (n + 63u) & ~63u;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
-        int cls = -1;
-        uint32_t p = 0;
-        if (i < n) {
-            p = queue ? queue[i] : i;
-            const int32_t hp = ps.hprim[p];
-            if (hp < 0) cls = 0;
-            else {
-                const cray_prim pr = sc.prims[hp];
-                cls = pr.light >= 0 ? 1 : 2 + (pr.material % (kShadeClasses - 2));
+    constexpr uint32_t kTile = 512;
+    __shared__ uint32_t lists[kShadeClasses][kTile];
+    __shared__ unsigned int cnt[kShadeClasses], base[kShadeClasses];
+    const uint32_t n_tiles = (n + kTile - 1) / kTile;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        if (threadIdx.x < kShadeClasses) cnt[threadIdx.x] = 0;
+        __syncthreads();
+        for (uint32_t k = 0; k < kTile / kBlock; k++) {
+            const uint32_t i = tile * kTile + k * kBlock + threadIdx.x;
+            int cls = -1;
+            uint32_t p = 0;
+            if (i < n) {
+                p = queue ? queue[i] : i;
+                const int32_t hp = ps.hprim[p];
+                if (hp < 0) cls = 0;
+                else {
+                    const cray_prim pr = sc.prims[hp];
+                    cls = pr.light >= 0 ? 1 : 2 + (pr.material % (kShadeClasses - 2));
+                }
             }
-        }
 #pragma unroll
-        for (int c = 0; c < kShadeClasses; c++) queue_push(class_queues + (size_t)c * class_stride, class_counts + c, cls == c, p);
+            for (int c = 0; c < kShadeClasses; c++) queue_push(lists[c], &cnt[c], cls == c, p);
+        }
+        __syncthreads();
+        if (threadIdx.x < kShadeClasses) base[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(class_counts + threadIdx.x, cnt[threadIdx.x]) : 0u;
+        __syncthreads();
+        for (int c = 0; c < kShadeClasses; c++)
+            for (uint32_t j = threadIdx.x; j < cnt[c]; j += kBlock) class_queues[(size_t)c * class_stride + base[c] + j] = lists[c][j];
+        __syncthreads();
     }
 }
 
