@@ -93,6 +93,7 @@ __global__ void __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace(DevScene sc,
     } while (0)
     int sp = 0;
     bool active = false, exhausted = false;
+    bool pending = false;  // ray finished, result still in registers (written at the next refill)
     unsigned int res_base = 0, res_left = 0;  // wave-uniform reserve of queue positions
     unsigned int chunk = n / (gridDim.x * (kBlock / 64) * 4u);
     chunk = chunk < 64u ? 64u : (chunk > 512u ? 512u : chunk);
@@ -106,7 +107,20 @@ __global__ void __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace(DevScene sc,
         // positions with ONE atomic and hands them out over several refills, so that most refills do not
         // start with a device-wide atomic round trip.
         const unsigned long long idle = __ballot(!active);
-        if ((unsigned int)__popcll(idle) >= refill_min && !exhausted) {
+        const bool do_refill = (unsigned int)__popcll(idle) >= refill_min && !exhausted;
+        // Results of finished rays stay in registers until the wave refills (or drains): the stores then
+        // run once with many lanes instead of in almost every iteration with one or two.
+        if ((do_refill || idle == ~0ull) && pending) {
+            if (ANY) {
+                ps.lr[p] = ps.lr[p] + ps.cr[p];
+                ps.lg[p] = ps.lg[p] + ps.cg[p];
+                ps.lb[p] = ps.lb[p] + ps.cb[p];
+            } else {
+                ps.ht[p] = hit_t; ps.hu[p] = hit_u; ps.hv[p] = hit_v; ps.hprim[p] = hit_prim;
+            }
+            pending = false;
+        }
+        if (do_refill) {
             if (res_left == 0) {
                 const unsigned int leader = __ffsll((long long)idle) - 1;
                 unsigned int base = 0;
@@ -137,12 +151,8 @@ __global__ void __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace(DevScene sc,
                 if (child_key(sc.root_lo, sc.root_hi, ray.o, ray.d) < ray.tmax) {
                     cur = sc.root_ref;
                     active = true;
-                } else if (ANY) {  // root rejected: unoccluded
-                    ps.lr[p] = ps.lr[p] + ps.cr[p];
-                    ps.lg[p] = ps.lg[p] + ps.cg[p];
-                    ps.lb[p] = ps.lb[p] + ps.cb[p];
                 } else {
-                    ps.ht[p] = 0.0; ps.hu[p] = 0.0; ps.hv[p] = 0.0; ps.hprim[p] = -1;
+                    pending = true;  // root rejected: miss / unoccluded
                 }
             }
         }
@@ -231,15 +241,7 @@ __global__ void __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace(DevScene sc,
             }
         }
         if (active && finished) {
-            if (ANY) {
-                if (!occluded) {
-                    ps.lr[p] = ps.lr[p] + ps.cr[p];
-                    ps.lg[p] = ps.lg[p] + ps.cg[p];
-                    ps.lb[p] = ps.lb[p] + ps.cb[p];
-                }
-            } else {
-                ps.ht[p] = hit_t; ps.hu[p] = hit_u; ps.hv[p] = hit_v; ps.hprim[p] = hit_prim;
-            }
+            pending = ANY ? !occluded : true;
             active = false;
         }
     }
