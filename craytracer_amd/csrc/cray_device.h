@@ -76,6 +76,7 @@ struct DevScene {
     // BVH
     double root_lo[3], root_hi[3];
     uint32_t root_ref, n_inner;
+    uint32_t bounds_in_div_range, pad_div_;  // every node bound is 0 or within [2^-500, 2^500]: div_fast is exact
     const InnerNode* inner;
     const LeafSlot* slots;
     // primitives

@@ -298,6 +298,10 @@ extern "C" int cray_scene_upload(cray_ctx* c, const cray_flat_scene* f, cray_sce
     for (int k = 0; k < 3; k++) { d.root_lo[k] = f->nodes[0].bmin[k]; d.root_hi[k] = f->nodes[0].bmax[k]; }
     int e = make_ref(0, &d.root_ref);
     d.n_inner = n_inner;
+    d.bounds_in_div_range = 1;
+    for (uint32_t i = 0; i < f->n_nodes && d.bounds_in_div_range; i++)
+        for (int k = 0; k < 3; k++)
+            if (!div_range_ok(f->nodes[i].bmin[k]) || !div_range_ok(f->nodes[i].bmax[k])) d.bounds_in_div_range = 0;
 
     // triangle shading records, in triangle-table order
     std::vector<TriShade> shade(f->n_triangles);

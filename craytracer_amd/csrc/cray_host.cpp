@@ -507,3 +507,14 @@ extern "C" void cray_host_sincos(double x, double* s, double* c) {
     if (s) *s = sv;
     if (c) *c = cv;
 }
+
+extern "C" uint64_t cray_host_div_fast_mismatches(const double* a, const double* d, uint64_t n) {
+    uint64_t bad = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        if (!cray::div_fast_ok(d[i]) || !cray::div_range_ok(a[i])) continue;
+        const double y = 1.0 / d[i];
+        const double q = cray::div_fast(a[i], d[i], y), ref = a[i] / d[i];
+        if (memcmp(&q, &ref, 8) != 0 && !(q == 0.0 && ref == 0.0)) bad++;  // the sign of a zero quotient is immaterial to the slab test
+    }
+    return bad;
+}

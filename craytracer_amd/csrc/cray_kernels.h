@@ -50,6 +50,28 @@ __device__ __forceinline__ double child_key(const double* __restrict__ lo, const
     return inside ? -inf64() : key;
 }
 
+// child_key with the six divisions replaced by the exact FMA sequence of cray_math.h (div_fast):
+// identical bits, about half the VALU instructions.  rd = 1/d per axis, computed once per ray.
+__device__ __forceinline__ double child_key_fast(const double* __restrict__ lo, const double* __restrict__ hi, vec3 o, vec3 d, vec3 rd) {
+    double tmin = -inf64(), tmax = inf64();
+#pragma unroll
+    for (int ax = 0; ax < 3; ax++) {
+        double d_i = ax == 0 ? d.x : (ax == 1 ? d.y : d.z);
+        double o_i = ax == 0 ? o.x : (ax == 1 ? o.y : o.z);
+        double y_i = ax == 0 ? rd.x : (ax == 1 ? rd.y : rd.z);
+        double mn = lo[ax], mx = hi[ax];
+        if (sign_neg(d_i)) { double t = mn; mn = mx; mx = t; }
+        tmax = min_nn(tmax, div_fast(mx - o_i, d_i, y_i));
+        tmin = max_nn(tmin, div_fast(mn - o_i, d_i, y_i));
+    }
+    bool ok = !(tmax < kEps) && !(tmin > tmax);
+    bool inside = lo[0] <= o.x && lo[1] <= o.y && lo[2] <= o.z && hi[0] >= o.x && hi[1] >= o.y && hi[2] >= o.z;
+    double a = tmin > kEps ? tmin : inf64();
+    double b = tmax > kEps ? tmax : inf64();
+    double key = ok ? min_nn(a, b) : inf64();
+    return inside ? -inf64() : key;
+}
+
 // ---------------------------------------------------------------------------------
 // Scene::intersect / Scene::intersects over a queue of paths — persistent wavefront tracer.
 //
@@ -99,6 +121,8 @@ __global__ void __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace(DevScene sc,
     chunk = chunk < 64u ? 64u : (chunk > 512u ? 512u : chunk);
     uint32_t p = 0, cur = 0;
     ray_t ray = mkray(mk(0, 0, 0), mk(0, 0, 1));
+    vec3 rd = mk(0, 0, 1);   // 1 / ray.d per axis (exact-division helper)
+    bool fast_div = false;   // operands of this ray are inside div_fast's proven range
     double hit_t = 0.0, hit_u = 0.0, hit_v = 0.0;
     int32_t hit_prim = -1;
 
@@ -147,6 +171,9 @@ __global__ void __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace(DevScene sc,
                 }
                 hit_t = 0.0; hit_u = 0.0; hit_v = 0.0; hit_prim = -1;
                 sp = 0;
+                rd = mk(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
+                fast_div = sc.bounds_in_div_range && div_fast_ok(ray.d.x) && div_fast_ok(ray.d.y) && div_fast_ok(ray.d.z) &&
+                           div_range_ok(ray.o.x) && div_range_ok(ray.o.y) && div_range_ok(ray.o.z);
                 if (COUNT) n_nodes += 1;
                 if (child_key(sc.root_lo, sc.root_hi, ray.o, ray.d) < ray.tmax) {
                     cur = sc.root_ref;
@@ -179,8 +206,9 @@ __global__ void __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace(DevScene sc,
             const unsigned long long refs = (unsigned long long)__double_as_longlong(r6.x);
             const uint32_t ref0 = (uint32_t)refs, ref1 = (uint32_t)(refs >> 32);
             const uint32_t axis = (uint32_t)(unsigned long long)__double_as_longlong(r6.y);
-            const double k0 = child_key(lo0, hi0, ray.o, ray.d);
-            const double k1 = child_key(lo1, hi1, ray.o, ray.d);
+            double k0, k1;
+            if (fast_div) { k0 = child_key_fast(lo0, hi0, ray.o, ray.d, rd); k1 = child_key_fast(lo1, hi1, ray.o, ray.d, rd); }
+            else { k0 = child_key(lo0, hi0, ray.o, ray.d); k1 = child_key(lo1, hi1, ray.o, ray.d); }
             // bvh.rs:92-98: dir[axis] < 0 -> push left, push right => right is visited first
             const bool right_first = comp(ray.d, (int)axis) < 0.0;
             const uint32_t near = right_first ? ref1 : ref0, far = right_first ? ref0 : ref1;

@@ -141,6 +141,34 @@ CRAY_HD ray_t xf_ray(const double* m, const ray_t& r) {  // :456-462
 }
 
 }  // namespace cray
+// -----------------------------------------------------------------------------------------
+// Exact division by a per-ray constant (used by the slab tests of the traversal kernel).
+//
+// The reference divides: (bound - origin) / direction, six times per box.  A correctly rounded
+// f64 division costs ~11 dependent VALU instructions on gfx950 (v_div_scale x2, v_rcp, 5 fma,
+// v_div_fmas, v_div_fixup).  With y = RN(1/d) computed ONCE per ray by a true division, the
+// quotient is recovered exactly by two FMA-based correction steps (Markstein 1990; Muller et al.,
+// Handbook of Floating-Point Arithmetic, Newton-Raphson division with FMA):
+//     q0 = RN(a*y)                         (within 2 ulp of a/d)
+//     q1 = RN(q0 + (a - q0*d) * y)         (faithful: within 1 ulp; the residual is exact in an FMA)
+//     q2 = RN(q1 + (a - q1*d) * y)         (= RN(a/d) by Markstein's theorem: y correctly rounded, q1 faithful)
+// valid when nothing over/underflows: the caller guarantees that a and d are zero or within
+// [2^-500, 2^500] in magnitude and d != 0 (div_fast_ok / scene check); otherwise it divides plainly.
+// tests/test_host_and_abi.py checks q2 == a/d bit for bit on random and adversarial operands.
+// -----------------------------------------------------------------------------------------
+namespace cray {
+CRAY_HD bool div_range_ok(double x) {  // 0 or 2^-500 <= |x| <= 2^500
+    const double ax = fabs(x);
+    return x == 0.0 || (ax >= 0x1p-500 && ax <= 0x1p500);
+}
+CRAY_HD bool div_fast_ok(double d) { return d != 0.0 && div_range_ok(d); }
+CRAY_HD double div_fast(double a, double d, double y) {
+    const double q0 = a * y;
+    const double q1 = fma(fma(-q0, d, a), y, q0);
+    return fma(fma(-q1, d, a), y, q1);
+}
+}  // namespace cray
+
 
 // -----------------------------------------------------------------------------------------
 // Correctly rounded sin / cos for the sampling routines (sample_disk, sample_sphere).

@@ -38,6 +38,11 @@ void cray_host_scene_free(cray_host_scene* scene);
  * (src/sampling.rs:17-39), evaluated on the host by the very same code (cray_math.h). */
 void cray_host_sincos(double x, double* sin_out, double* cos_out);
 
+/* The exact FMA-based division the traversal kernel uses for (bound - origin) / direction
+ * (cray_math.h div_fast): returns the number of i in [0,n) with div_fast(a[i], d[i], 1/d[i]) != a[i]/d[i]
+ * bitwise, among the pairs that pass the range guard. */
+uint64_t cray_host_div_fast_mismatches(const double* a, const double* d, uint64_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -137,3 +137,24 @@ def test_sincos_cr_equals_binary128_rounding():
         lib.cray_host_sincos(float(x), C.byref(s), C.byref(c))
         bad += (s.value != L.orc_sample_sin(float(x))) + (c.value != L.orc_sample_cos(float(x)))
     assert bad == 0
+
+
+def test_div_fast_is_the_correctly_rounded_quotient():
+    """cray_math.h div_fast (two FMA corrections on a*RN(1/d)) must equal a/d bit for bit: it replaces
+    the reference's divisions in the slab test.  Random, adversarial (quotients next to products,
+    divisor mantissas with long runs of ones) and scene-like operands."""
+    L = backend.lib()
+    rng = np.random.default_rng(0)
+    n = 2_000_000
+    cases = []
+    cases.append((rng.standard_normal(n) * 10.0 ** rng.integers(-8, 8, n), rng.standard_normal(n) * 10.0 ** rng.integers(-3, 3, n)))
+    q, d = rng.uniform(1, 2, n), rng.uniform(1, 2, n) * rng.choice([-1, 1], n)
+    cases.append((np.nextafter(q * d, rng.choice([-np.inf, np.inf], n)), d))
+    m = rng.integers(0, 2 ** 52, n, dtype=np.uint64) | rng.choice(
+        np.array([0, (1 << 52) - 1, (1 << 26) - 1, ((1 << 26) - 1) << 26], dtype=np.uint64), n)
+    cases.append((rng.uniform(-1e3, 1e3, n), (m | np.uint64(0x3ff0000000000000)).view(np.float64)))
+    cases.append((rng.uniform(-200, 200, n) - rng.uniform(-200, 200, n), np.cos(rng.uniform(0, np.pi, n))))
+    cases.append((np.zeros(n), rng.standard_normal(n)))
+    for a, d in cases:
+        a, d = np.ascontiguousarray(a, dtype=np.float64), np.ascontiguousarray(d, dtype=np.float64)
+        assert L.cray_host_div_fast_mismatches(a.ctypes.data, d.ctypes.data, n) == 0
