@@ -212,54 +212,97 @@ CRAY_HD dd dd_mul(dd a, dd b) {
     return dd_quick_two_sum(p.hi, p.lo);
 }
 
+CRAY_HD dd dd_mul_d(dd a, double b) {
+    dd p = dd_two_prod(a.hi, b);
+    p.lo += a.lo * b;
+    return dd_quick_two_sum(p.hi, p.lo);
+}
+CRAY_HD dd dd_neg(dd a) { return dd{-a.hi, -a.lo}; }
+
 CRAY_HD void sincos_cr(double x, double& s_out, double& c_out) {
     // pi/2 = P1 + P2 + P3 + P4; P1..P3 carry 33 significant bits, so k * Pi is exact for |k| < 2^20
     const double P1 = 0x1.921fb54400000p+0, P2 = 0x1.0b4611a600000p-34, P3 = 0x1.3198a2e000000p-69, P4 = 0x1.b839a252049c1p-104;
-    const double k = rint(x * 0x1.45f306dc9c883p-1);  // nearest multiple of pi/2
-    const double t = x - k * P1;    // exact: Sterbenz for k != 0
-    dd r = dd_two_sum(t, -(k * P2));
-    r = dd_add(r, dd{-(k * P3), 0.0});
-    r = dd_add(r, dd{-(k * P4), 0.0});
-    const dd r2 = dd_mul(r, r);
-    // (-1)^j / (2j+1)!  and  (-1)^j / (2j)!  as double-doubles
-    const double S[14][2] = {
-        {0x1.0000000000000p+0, 0x0.0p+0},
-        {-0x1.5555555555555p-3, -0x1.5555555555555p-57},
-        {0x1.1111111111111p-7, 0x1.1111111111111p-63},
-        {-0x1.a01a01a01a01ap-13, -0x1.a01a01a01a01ap-73},
-        {0x1.71de3a556c734p-19, -0x1.c154f8ddc6c00p-73},
-        {-0x1.ae64567f544e4p-26, 0x1.c062e06d1f209p-80},
-        {0x1.6124613a86d09p-33, 0x1.f28e0cc748ebep-87},
-        {-0x1.ae7f3e733b81fp-41, -0x1.1d8656b0ee8cbp-97},
-        {0x1.952c77030ad4ap-49, 0x1.ac981465ddc6cp-103},
-        {-0x1.2f49b46814157p-57, -0x1.2650f61dbdcb4p-112},
-        {0x1.71b8ef6dcf572p-66, -0x1.d043ae40c4647p-120},
-        {-0x1.761b41316381ap-75, 0x1.3423c7d91404fp-130},
-        {0x1.3f3ccdd165fa9p-84, -0x1.58ddadf344487p-139},
-        {-0x1.d1ab1c2dccea3p-94, -0x1.054d0c78aea14p-149}};
-    const double C[15][2] = {
-        {0x1.0000000000000p+0, 0x0.0p+0},
-        {-0x1.0000000000000p-1, 0x0.0p+0},
-        {0x1.5555555555555p-5, 0x1.5555555555555p-59},
-        {-0x1.6c16c16c16c17p-10, 0x1.f49f49f49f49fp-65},
-        {0x1.a01a01a01a01ap-16, 0x1.a01a01a01a01ap-76},
-        {-0x1.27e4fb7789f5cp-22, -0x1.cbbc05b4fa99ap-76},
-        {0x1.1eed8eff8d898p-29, -0x1.2aec959e14c06p-83},
-        {-0x1.93974a8c07c9dp-37, -0x1.05d6f8a2efd1fp-92},
-        {0x1.ae7f3e733b81fp-45, 0x1.1d8656b0ee8cbp-101},
-        {-0x1.6827863b97d97p-53, -0x1.eec01221a8b0bp-107},
-        {0x1.e542ba4020225p-62, 0x1.ea72b4afe3c2fp-120},
-        {-0x1.0ce396db7f853p-70, 0x1.aebcdbd20331cp-124},
-        {0x1.f2cf01972f578p-80, -0x1.9ada5fcc1ab14p-135},
-        {-0x1.88e85fc6a4e5ap-89, 0x1.71c37ebd16540p-143},
-        {0x1.0a18a2635085dp-98, 0x1.b9e2e28e1aa54p-153}};
-    dd ps = dd{S[13][0], S[13][1]};
-    for (int j = 12; j >= 0; j--) ps = dd_add(dd_mul(ps, r2), dd{S[j][0], S[j][1]});
-    dd pc = dd{C[14][0], C[14][1]};
-    for (int j = 13; j >= 0; j--) pc = dd_add(dd_mul(pc, r2), dd{C[j][0], C[j][1]});
-    const dd sr = dd_mul(ps, r);
-    const double sv = sr.hi + sr.lo, cv = pc.hi + pc.lo;
-    const int q = ((int)k) & 3;
+    const double kq = rint(x * 0x1.45f306dc9c883p-1);  // nearest multiple of pi/2
+    const double t = x - kq * P1;                       // exact: Sterbenz for kq != 0
+    dd r = dd_two_sum(t, -(kq * P2));
+    r = dd_add(r, dd{-(kq * P3), 0.0});
+    r = dd_add(r, dd{-(kq * P4), 0.0});                 // |r| <= pi/4 (+ rounding), ~2^-120 accurate
+    // r = +-(h + l), h = k/64 from a table of sin(h), cos(h) as double-doubles, |l| <= 2^-7
+    const bool neg = r.hi < 0.0;
+    if (neg) r = dd_neg(r);
+    const double kf = rint(r.hi * 64.0);
+    const int k = (int)kf;
+    const dd l = dd_add(r, dd{-(kf * 0.015625), 0.0});
+    const double kTab[52][4] = {
+        {0x0.0p+0, 0x0.0p+0, 0x1.0000000000000p+0, 0x0.0p+0},
+        {0x1.fffaaaaeeeed5p-7, -0x1.2ab639a9f0776p-63, 0x1.fff000155549fp-1, 0x1.28a28a03a5ef3p-55},
+        {0x1.ffeaaaeeee86fp-6, -0x1.cd406fb224ae2p-60, 0x1.ffc00155527d3p-1, -0x1.3b54492d89b5bp-55},
+        {0x1.7fdc01032fba9p-5, -0x1.599bdf46e997ap-59, 0x1.ff7006bfdf99fp-1, -0x1.8b3b560648d5fp-56},
+        {0x1.ffaaaeeed4edbp-5, -0x1.2d16d32684b69p-59, 0x1.ff0015549f4d3p-1, 0x1.328387b99426fp-55},
+        {0x1.3facb12d1755bp-4, -0x1.921915299468bp-58, 0x1.fe7034129ef6fp-1, -0x1.cbf4337c96f97p-57},
+        {0x1.7f701032550e4p-4, 0x1.afc2d1800501ap-60, 0x1.fdc06bf7e6b9bp-1, 0x1.31902b535f8dbp-55},
+        {0x1.bf1b78568391dp-4, 0x1.e91841dea4cc8p-58, 0x1.fcf0c800e99b1p-1, 0x1.ea3d786d186acp-57},
+        {0x1.feaaeee86ee36p-4, -0x1.afcb2bcc6f03bp-59, 0x1.fc015527d5bd3p-1, 0x1.b68f35094efb8p-55},
+        {0x1.1f0d3d7afceafp-3, -0x1.6ef95099769a5p-57, 0x1.faf22263c4bd3p-1, -0x1.52ace133a2769p-58},
+        {0x1.3eb312c5d66cbp-3, 0x1.47d666b66cb91p-57, 0x1.f9c340a7cc428p-1, 0x1.c5b6b063b7462p-55},
+        {0x1.5e44fcfa126f3p-3, -0x1.6f443063f89b6p-57, 0x1.f874c2e1eecf6p-1, -0x1.c6514e1332b16p-55},
+        {0x1.7dc102fbaf2b5p-3, 0x1.5ab50e23c97c3p-59, 0x1.f706bdf9ece1cp-1, -0x1.698c80c36dcb4p-55},
+        {0x1.9d252d0cec312p-3, 0x1.9c43d80b1137dp-58, 0x1.f57948cff6797p-1, 0x1.e3a0d3e03b1d4p-57},
+        {0x1.bc6f84edc6199p-3, 0x1.9c1a56a7b0cabp-57, 0x1.f3cc7c3b3d16ep-1, -0x1.21a3ad28a3494p-57},
+        {0x1.db9e15fb5a5d0p-3, -0x1.32e20d6cc6fc2p-57, 0x1.f20073086649fp-1, 0x1.b940416c1984bp-56},
+        {0x1.faaeed4f31577p-3, -0x1.15d88508e32b8p-57, 0x1.f01549f7deea1p-1, 0x1.d3c1e99e5cafdp-55},
+        {0x1.0cd00cef36436p-2, -0x1.9fb0a0c93e2b4p-56, 0x1.ee0b1fbc0f11cp-1, -0x1.bfd2380bbc3b1p-59},
+        {0x1.1c37d64c6b876p-2, 0x1.46076fe0dcff4p-56, 0x1.ebe214f76efa8p-1, -0x1.02f9f12ba543ep-55},
+        {0x1.2b8ddc43eb49fp-2, 0x1.1553899f2d807p-57, 0x1.e99a4c3a7cd83p-1, -0x1.2264b1bc53ce8p-55},
+        {0x1.3ad129769d3d8p-2, 0x1.03d550487839ap-63, 0x1.e733ea0193d40p-1, -0x1.6428b3546ce13p-55},
+        {0x1.4a00c9b0f3d20p-2, 0x1.823ba6bb08eadp-56, 0x1.e4af14b2a449cp-1, -0x1.68ca02e8a6833p-55},
+        {0x1.591bc9fa2f597p-2, 0x1.7c74bac3fe0cbp-57, 0x1.e20bf49acd6c1p-1, -0x1.660aec7ef636bp-58},
+        {0x1.682138a38d7f7p-2, -0x1.d889202444aadp-56, 0x1.df4ab3ebd875ep-1, -0x1.e2d8a7e6736c4p-55},
+        {0x1.7710255764214p-2, -0x1.6ead7314bb6cep-57, 0x1.dc6b7eb995912p-1, 0x1.4b364776dcd35p-58},
+        {0x1.85e7a12826949p-2, 0x1.8a40e9b5face0p-56, 0x1.d96e82f71a9dcp-1, 0x1.ff61bd5d2039dp-55},
+        {0x1.94a6be9f546c5p-2, -0x1.69ce13e683f58p-56, 0x1.d653f073e4040p-1, -0x1.76236434bec37p-55},
+        {0x1.a34c91cc50ccap-2, -0x1.a310e3b50cecdp-58, 0x1.d31bf8d8d7c06p-1, 0x1.e60dd3089cbddp-56},
+        {0x1.b1d8305321617p-2, -0x1.ae242cb99f519p-56, 0x1.cfc6cfa52ad9fp-1, 0x1.8b5b5508f2a0dp-55},
+        {0x1.c048b17b140a3p-2, 0x1.19fe6757e9fa7p-57, 0x1.cc54aa2b2972ep-1, 0x1.4ee162ba83a98p-57},
+        {0x1.ce9d2e3d4a51fp-2, -0x1.2fc8a12dae298p-57, 0x1.c8c5bf8ce1a84p-1, 0x1.ab3d1a1590123p-56},
+        {0x1.dcd4c15329c9ap-2, 0x1.0d4c6e171fd9ap-56, 0x1.c51a48b8b175ep-1, -0x1.1bbb43b9aa880p-57},
+        {0x1.eaee8744b05f0p-2, -0x1.789b43c9b027dp-58, 0x1.c1528065b7d50p-1, -0x1.892111312e828p-55},
+        {0x1.f8e99e76abc97p-2, 0x1.9d950af2d00a3p-58, 0x1.bd6ea310294f5p-1, 0x1.31bbcc88c109dp-56},
+        {0x1.0362939c69955p-1, -0x1.2d8cd78397b01p-55, 0x1.b96eeef58840ep-1, 0x1.45a3cc78fade0p-58},
+        {0x1.0a4021e9e1001p-1, -0x1.6f643a13914f6p-55, 0x1.b553a410c104ep-1, 0x1.8ff7947027a15p-58},
+        {0x1.110d0c4b69c3bp-1, 0x1.d918998809981p-55, 0x1.b11d04162a4c6p-1, 0x1.1dd561efbc0c2p-56},
+        {0x1.17c8e5f2eedb0p-1, 0x1.35e57102e2488p-57, 0x1.accb526f69de5p-1, 0x1.8fb6a8dd6b6ccp-55},
+        {0x1.1e7343236574cp-1, 0x1.22a3fa4f41d5ap-56, 0x1.a85ed4373e02dp-1, 0x1.9be06385ec792p-57},
+        {0x1.250bb93788bbbp-1, 0x1.ea3d02457bccep-56, 0x1.a3d7d0352bdcfp-1, -0x1.68dbaeca19669p-55},
+        {0x1.2b91dea88421ep-1, -0x1.fa371db216ab0p-55, 0x1.9f368ed912f85p-1, -0x1.1d200c5791606p-55},
+        {0x1.32054b148bc4fp-1, 0x1.f6b42095a135bp-55, 0x1.9a7b5a36a6514p-1, 0x1.722cfcc9fa7a9p-55},
+        {0x1.386597456282bp-1, -0x1.10fada93b07a8p-56, 0x1.95a67e00cb1fdp-1, -0x1.0befda21f862dp-55},
+        {0x1.3eb25d36cd53ap-1, -0x1.be570e1570fc0p-58, 0x1.90b84784ddaf7p-1, -0x1.0feb10ab93b87p-56},
+        {0x1.44eb381cf386bp-1, -0x1.3ed6c1e6a5505p-55, 0x1.8bb105a5dc900p-1, 0x1.863e03e9474c1p-55},
+        {0x1.4b0fc46aab761p-1, 0x1.0da05738cc59cp-61, 0x1.869108d77a6c6p-1, 0x1.338ffe2bfe9ddp-56},
+        {0x1.511f9fd7b351cp-1, -0x1.5c0e861c48831p-55, 0x1.8158a31916d5dp-1, -0x1.de8b90b8228dep-57},
+        {0x1.571a6966d59b3p-1, 0x1.c843b4d0fb197p-58, 0x1.7c0827f09e54fp-1, -0x1.c73d6d72aee68p-57},
+        {0x1.5cffc16bf8f0dp-1, 0x1.96cb370eb578ap-55, 0x1.769fec655211fp-1, -0x1.827d5cf8c68c5p-57},
+        {0x1.62cf49921ac79p-1, -0x1.edd9855b6241ap-55, 0x1.712046fa77678p-1, 0x1.425b0a5029c81p-55},
+        {0x1.6888a4e134b2fp-1, -0x1.6b7d37644d5e6p-55, 0x1.6b898fa9efb5dp-1, 0x1.15ac786ccf4b2p-56},
+        {0x1.6e2b77c40bde1p-1, -0x1.0e729857fad53p-56, 0x1.65dc1fdeb8cbap-1, -0x1.97c1b47337c77p-58}};
+    const dd S = dd{kTab[k][0], kTab[k][1]}, C = dd{kTab[k][2], kTab[k][3]};
+    const dd l2 = dd_mul(l, l);
+    // sin(l)/l and cos(l): the two leading correction terms in double-double, the (tiny) tails in double
+    const double ts = -0x1.a01a01a01a01ap-13 + l2.hi * (0x1.71de3a556c734p-19 + l2.hi * -0x1.ae64567f544e4p-26);       // -1/7! + l2/9! - l2^2/11!
+    const double tc = -0x1.6c16c16c16c17p-10 + l2.hi * (0x1.a01a01a01a01ap-16 + l2.hi * (-0x1.27e4fb7789f5cp-22 + l2.hi * 0x1.1eed8eff8d898p-29));  // -1/6! + l2/8! - l2^2/10! + l2^3/12!
+    dd ps = dd_add(dd{0x1.1111111111111p-7, 0x1.1111111111111p-63}, dd_mul_d(l2, ts));       // 1/5! + ...
+    ps = dd_add(dd{-0x1.5555555555555p-3, -(0x1.5555555555555p-57)}, dd_mul(l2, ps));         // -1/3! + ...
+    ps = dd_add(dd{1.0, 0.0}, dd_mul(l2, ps));
+    const dd sl = dd_mul(l, ps);
+    dd pc = dd_add(dd{0x1.5555555555555p-5, 0x1.5555555555555p-59}, dd_mul_d(l2, tc));       // 1/4! + ...
+    pc = dd_add(dd{-0.5, 0.0}, dd_mul(l2, pc));
+    const dd cl = dd_add(dd{1.0, 0.0}, dd_mul(l2, pc));
+    dd sr = dd_add(dd_mul(S, cl), dd_mul(C, sl));        // sin(h + l)
+    const dd cr = dd_add(dd_mul(C, cl), dd_neg(dd_mul(S, sl)));
+    if (neg) sr = dd_neg(sr);
+    const double sv = sr.hi + sr.lo, cv = cr.hi + cr.lo;
+    const int q = ((int)kq) & 3;
     s_out = q == 0 ? sv : (q == 1 ? cv : (q == 2 ? -sv : -cv));
     c_out = q == 0 ? cv : (q == 1 ? -sv : (q == 2 ? -cv : sv));
 }
