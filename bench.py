@@ -86,14 +86,16 @@ def main():
             % (len(scene.triangles), host.flat.n_nodes, t1 - t0, t2 - t1, t3 - t2, dev.device_bytes / 1e9))
 
     film = torch.zeros((H, W, 3), dtype=torch.float32, device='cuda')
+    host_film = torch.empty((H, W, 3), dtype=torch.float32).pin_memory() if rank == 0 else None
 
     def frame():
         _, st = dev.render(seed=0, rank=rank, world_size=world, out_device_ptr=film.data_ptr())
         out = cdist.gather_film(film, W, H, rank, world)
         if rank == 0:
-            out = out.cpu()  # Film resident on the rank-0 host, like the Vec<f32> handed to on_render_finish
+            # Film resident on the rank-0 host, like the Vec<f32> handed to on_render_finish
+            host_film.copy_(out, non_blocking=True)
         torch.cuda.current_stream().synchronize()
-        return st, out
+        return st, host_film
 
     def barrier():
         if world > 1:

@@ -443,8 +443,12 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
         if (tm) { int e = tm->end(); if (e) return e; }
     }
     if (tm) { int e = tm->begin(FAM_OTHER); if (e) return e; }
-    hipLaunchKernelGGL(k_film, dim3(grid_for(c, pp.n_pix, 8)), dim3(kBlock), 0, st, c->ps, c->pix_list, pp.px0, pp.n_pix, spp_pass, pp.s_lo,
-                       prm.sample_batch, c->film, ctr);
+    {
+        const size_t groups = ((size_t)pp.n_pix + 63) / 64, cap = (size_t)c->n_cu * 32;  // one wave per block
+        const int g_film = (int)(groups < cap ? (groups ? groups : 1) : cap);
+        hipLaunchKernelGGL(k_film, dim3(g_film), dim3(64), 0, st, c->ps, c->pix_list, pp.px0, pp.n_pix, spp_pass, pp.s_lo,
+                           prm.sample_batch, c->film, ctr);
+    }
     if (tm) { int e = tm->end(); if (e) return e; }
     HIP_TRY(hipGetLastError());
     return CRAY_OK;

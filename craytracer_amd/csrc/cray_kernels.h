@@ -175,7 +175,9 @@ __global__ void __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace(DevScene sc,
                 fast_div = sc.bounds_in_div_range && div_fast_ok(ray.d.x) && div_fast_ok(ray.d.y) && div_fast_ok(ray.d.z) &&
                            div_range_ok(ray.o.x) && div_range_ok(ray.o.y) && div_range_ok(ray.o.z);
                 if (COUNT) n_nodes += 1;
-                if (child_key(sc.root_lo, sc.root_hi, ray.o, ray.d) < ray.tmax) {
+                const double k_root = fast_div ? child_key_fast(sc.root_lo, sc.root_hi, ray.o, ray.d, rd)
+                                               : child_key(sc.root_lo, sc.root_hi, ray.o, ray.d);
+                if (k_root < ray.tmax) {
                     cur = sc.root_ref;
                     active = true;
                 } else {
@@ -284,7 +286,9 @@ __global__ void __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace(DevScene sc,
 }
 
 // render_pixel up to the camera ray (craytracer.rs:148-156) for every path of a pass.
-// path p -> pixel pix_list[px0 + p / spp_pass], sample s_lo + p % spp_pass.
+// path p -> pixel pix_list[px0 + p / spp_pass], sample s_lo + p % spp_pass.  (Sample-major order was
+// measured: k_film gets trivially coalesced, but the traversal and k_shade lose the coherence of the 16
+// samples of one pixel sitting in adjacent lanes: +13 ms closest, +8 ms shade per frame.)
 __global__ void __launch_bounds__(kBlock) k_raygen(DevScene sc, PathState ps, const uint32_t* __restrict__ pix_list, uint32_t px0,
                                                    uint32_t n_paths, uint32_t spp_pass, uint32_t s_lo, uint64_t seed) {
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -563,27 +567,51 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
 
 // render_tile's accumulation (craytracer.rs:175-188): per pixel, each sample batch is summed in
 // f64 in sample order, cast to f32 and added into the f32 film; batches in ascending order.
-__global__ void __launch_bounds__(kBlock) k_film(PathState ps, const uint32_t* __restrict__ pix_list, uint32_t px0, uint32_t n_pix,
-                                                 uint32_t spp_pass, uint32_t s_lo, uint32_t batch, float* __restrict__ film, Counters* ctr) {
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t pl = blockIdx.x * blockDim.x + threadIdx.x; pl < n_pix; pl += stride) {
-        const uint32_t pix = pix_list[px0 + pl];
-        float fr = film[3 * (size_t)pix], fg = film[3 * (size_t)pix + 1], fb = film[3 * (size_t)pix + 2];
-        double cr = 0.0, cg = 0.0, cb = 0.0;
+// One wave per block handles 64 consecutive pixels of the pass.  A pixel's samples are contiguous in the
+// radiance arrays (path = pixel * spp_pass + sample), so a lane-per-pixel loop would read with a stride of
+// spp_pass * 8 B; instead the wave stages kFilmChunk samples of its 64 pixels through LDS with whole-line
+// loads (4 pixels x 128 B per load instruction) and each lane then sums ITS pixel's samples in ascending
+// order — the same f64 batch sums and f32 adds as before.
+constexpr uint32_t kFilmChunk = 16;
+__global__ void __launch_bounds__(64) k_film(PathState ps, const uint32_t* __restrict__ pix_list, uint32_t px0, uint32_t n_pix,
+                                             uint32_t spp_pass, uint32_t s_lo, uint32_t batch, float* __restrict__ film, Counters* ctr) {
+    __shared__ double stage[64 * (kFilmChunk + 1)];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n_groups = (n_pix + 63) / 64;
+    for (uint32_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const uint32_t pl0 = grp * 64, pl = pl0 + lane;
+        const bool live = pl < n_pix;
+        const uint32_t pix = live ? pix_list[px0 + pl] : 0u;
+        float f[3] = {0.f, 0.f, 0.f};
+        if (live) { f[0] = film[3 * (size_t)pix]; f[1] = film[3 * (size_t)pix + 1]; f[2] = film[3 * (size_t)pix + 2]; }
+        double acc[3] = {0.0, 0.0, 0.0};
         bool bad = false;
-        for (uint32_t j = 0; j < spp_pass; j++) {
-            const size_t p = (size_t)pl * spp_pass + j;
-            const double r = ps.lr[p], g = ps.lg[p], b = ps.lb[p];
-            if (!(isfinite(r) && isfinite(g) && isfinite(b))) bad = true;
-            cr += r; cg += g; cb += b;
-            const uint32_t s = s_lo + j;
-            if (((s + 1) % batch) == 0 || j + 1 == spp_pass) {
-                fr += (float)cr; fg += (float)cg; fb += (float)cb;
-                cr = 0.0; cg = 0.0; cb = 0.0;
+        for (uint32_t j0 = 0; j0 < spp_pass; j0 += kFilmChunk) {
+            const uint32_t nj = spp_pass - j0 < kFilmChunk ? spp_pass - j0 : kFilmChunk;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const double* __restrict__ src = ch == 0 ? ps.lr : (ch == 1 ? ps.lg : ps.lb);
+                __syncthreads();
+                for (uint32_t i = 0; i < 64 * kFilmChunk / 64; i++) {
+                    const uint32_t q = i * (64 / kFilmChunk) + lane / kFilmChunk, jj = lane % kFilmChunk;
+                    if (pl0 + q < n_pix && jj < nj) stage[q * (kFilmChunk + 1) + jj] = src[(size_t)(pl0 + q) * spp_pass + j0 + jj];
+                }
+                __syncthreads();
+                if (live) {
+                    for (uint32_t jj = 0; jj < nj; jj++) {
+                        const double v = stage[lane * (kFilmChunk + 1) + jj];
+                        if (!isfinite(v)) bad = true;
+                        acc[ch] += v;
+                        const uint32_t j = j0 + jj, sidx = s_lo + j;
+                        if (((sidx + 1) % batch) == 0 || j + 1 == spp_pass) { f[ch] += (float)acc[ch]; acc[ch] = 0.0; }
+                    }
+                }
             }
         }
-        film[3 * (size_t)pix] = fr; film[3 * (size_t)pix + 1] = fg; film[3 * (size_t)pix + 2] = fb;
-        if (bad) atomicAdd(&ctr->nonfinite, 1ull);
+        if (live) {
+            film[3 * (size_t)pix] = f[0]; film[3 * (size_t)pix + 1] = f[1]; film[3 * (size_t)pix + 2] = f[2];
+            if (bad) atomicAdd(&ctr->nonfinite, 1ull);
+        }
     }
 }
 

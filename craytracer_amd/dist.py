@@ -29,27 +29,57 @@ def max_rank_pixels(width, height, world_size, tile_w=64, tile_h=64):
     return max(len(rank_pixels(width, height, r, world_size, tile_w, tile_h)) for r in range(world_size))
 
 
+class FilmGather:
+    """Per-(film, rank, world) plan of the tile gather: index tensors and buffers are built once, a
+    frame then costs one index_select (pack), one `gather`, and on rank 0 one index_select (unpack)."""
+
+    def __init__(self, width, height, rank, world_size, device, group=None, tile_w=64, tile_h=64):
+        import torch
+
+        self.width, self.height, self.rank, self.world, self.group = width, height, rank, world_size, group
+        per_rank = [rank_pixels(width, height, r, world_size, tile_w, tile_h) for r in range(world_size)]
+        self.n_max = max(len(p) for p in per_rank)
+        # pack: row i of the packed buffer is pixel mine[i]; rows past len(mine) repeat pixel 0 (never read back)
+        mine = np.zeros(self.n_max, dtype=np.int64)
+        mine[: len(per_rank[rank])] = per_rank[rank]
+        self.mine = torch.from_numpy(mine).to(device)
+        self.packed = torch.empty((self.n_max, 3), dtype=torch.float32, device=device)
+        self.parts = None
+        if rank == 0:
+            # unpack: pixel p lives at row where[p] of the concatenated parts
+            where = np.zeros(width * height, dtype=np.int64)
+            for r, p in enumerate(per_rank):
+                where[p] = r * self.n_max + np.arange(len(p), dtype=np.int64)
+            self.where = torch.from_numpy(where).to(device)
+            self.parts = torch.empty((world_size, self.n_max, 3), dtype=torch.float32, device=device)
+            self.out = torch.empty((width * height, 3), dtype=torch.float32, device=device)
+
+    def gather(self, local_film):
+        import torch
+        import torch.distributed as dist
+
+        if self.world == 1:
+            return local_film
+        torch.index_select(local_film.reshape(-1, 3), 0, self.mine, out=self.packed)
+        if self.rank == 0:
+            dist.gather(self.packed, gather_list=list(self.parts.unbind(0)), dst=0, group=self.group)
+            torch.index_select(self.parts.reshape(-1, 3), 0, self.where, out=self.out)
+            return self.out.reshape(self.height, self.width, 3)
+        dist.gather(self.packed, gather_list=None, dst=0, group=self.group)
+        return None
+
+
+_plans = {}
+
+
 def gather_film(local_film, width, height, rank, world_size, group=None, tile_w=64, tile_h=64):
     """local_film: torch tensor [H, W, 3] float32 holding this rank's tiles (anything elsewhere).
-    Returns the assembled film on rank 0 (None on other ranks).  One `gather` of packed tiles."""
-    import torch
-    import torch.distributed as dist
-
+    Returns the assembled film on rank 0 (None on other ranks).  One `gather` of packed tiles;
+    the plan (index tensors, buffers) is cached per film geometry."""
     if world_size == 1:
         return local_film
-    dev = local_film.device
-    flat = local_film.reshape(-1, 3)
-    n_max = max_rank_pixels(width, height, world_size, tile_w, tile_h)
-    mine = torch.from_numpy(rank_pixels(width, height, rank, world_size, tile_w, tile_h)).to(dev)
-    packed = torch.zeros((n_max, 3), dtype=torch.float32, device=dev)
-    packed[: len(mine)] = flat[mine]
-    if rank == 0:
-        parts = [torch.empty_like(packed) for _ in range(world_size)]
-        dist.gather(packed, gather_list=parts, dst=0, group=group)
-        out = torch.zeros_like(flat)
-        for r in range(world_size):
-            idx = torch.from_numpy(rank_pixels(width, height, r, world_size, tile_w, tile_h)).to(dev)
-            out[idx] = parts[r][: len(idx)]
-        return out.reshape(height, width, 3)
-    dist.gather(packed, gather_list=None, dst=0, group=group)
-    return None
+    key = (width, height, rank, world_size, str(local_film.device), id(group), tile_w, tile_h)
+    plan = _plans.get(key)
+    if plan is None:
+        plan = _plans[key] = FilmGather(width, height, rank, world_size, local_film.device, group, tile_w, tile_h)
+    return plan.gather(local_film)

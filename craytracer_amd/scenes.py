@@ -212,7 +212,7 @@ def staircase(width=1920, height=1080, spp=256, max_depth=12, detail=1.0, seed=0
         else:            # Plastic + specular, Lambert diffuse
             mats.append(S.Material.new_plastic(tex, S.Color(0.04, 0.04, 0.04), rough(0.0)))
 
-    n = max(2, int(160 * detail))
+    n = max(2, int(224 * detail))
     meshes = []
 
     def add(origin, du, dv, mat, bump=0.0, res=n):
