@@ -31,6 +31,7 @@ def main(argv=None):
     ap.add_argument('--spp', type=int, default=0)
     ap.add_argument('--max-depth', type=int, default=0)
     ap.add_argument('--device', type=int, default=0)
+    ap.add_argument('--host-bvh', action='store_true', help='build the BVH on the host (default: on the GPU)')
     args = ap.parse_args(argv)
 
     from . import backend, cry
@@ -42,9 +43,10 @@ def main(argv=None):
         loc = '%s:%d:%d' % (args.scene, e.location[0], e.location[1]) if e.location else args.scene
         print('%s %s %s' % (e.message, 'at' if e.location else 'in', loc), file=sys.stderr)
         return 0
-    host = backend.HostScene(scene)
+    ctx = backend.Context(args.device)
+    host = backend.HostScene(scene, bvh_ctx=None if args.host_bvh else ctx)  # Bvh::new on the GPU: same tree
     print('Scene constructed in %.1fs' % (time.time() - start), file=sys.stderr)
-    dev = backend.Context(args.device).upload(host)
+    dev = ctx.upload(host)
     film, st = dev.render(seed=args.seed)
     print('Rendering finished in %.3fs (%.1f Mray/s)' % (st['seconds'], (st['closest_rays'] + st['shadow_rays'] - st['shadow_skipped']) / st['seconds'] / 1e6), file=sys.stderr)
     if args.output.endswith('.npy'):

@@ -65,10 +65,17 @@ class FlatScene(C.Structure):
 
 
 #: every symbol include/cray.h and include/cray_host.h declare
+class BvhBuildStats(C.Structure):
+    """cray_bvh_build_stats (include/cray.h)."""
+    _fields_ = [('device_seconds', C.c_double), ('total_seconds', C.c_double), ('levels', C.c_uint32),
+                ('top_nodes', C.c_uint32), ('small_subtrees', C.c_uint32), ('leaves', C.c_uint32)]
+
+
 ABI_SYMBOLS = ['cray_ctx_create', 'cray_ctx_destroy', 'cray_scene_upload', 'cray_scene_free',
                'cray_scene_device_bytes', 'cray_render', 'cray_render_params_default', 'cray_render_samples',
                'cray_trace', 'cray_last_error', 'cray_host_scene_new', 'cray_host_scene_flat',
-               'cray_host_scene_build_seconds', 'cray_host_scene_free', 'cray_host_sincos', 'cray_host_div_fast_mismatches',
+               'cray_host_scene_build_seconds', 'cray_host_scene_free', 'cray_host_scene_new_on',
+               'cray_host_scene_bvh_seconds', 'cray_bvh_build_sah', 'cray_host_sincos', 'cray_host_div_fast_mismatches',
                'cray_cry_tokenize', 'cray_cry_free_tokens', 'cray_cry_parse_value', 'cray_cry_free_string',
                'cray_cry_parse_scene', 'cray_owned_scene_desc', 'cray_owned_scene_warnings', 'cray_owned_scene_free']
 
@@ -103,6 +110,11 @@ def lib():
     L.cray_render_samples.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(RenderParams), C.c_void_p]
     L.cray_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.POINTER(Stats)]
     L.cray_host_scene_new.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    L.cray_host_scene_new_on.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.cray_host_scene_bvh_seconds.restype = C.c_double
+    L.cray_host_scene_bvh_seconds.argtypes = [C.c_void_p, C.POINTER(BvhBuildStats)]
+    L.cray_bvh_build_sah.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32),
+                                     C.c_void_p, C.POINTER(BvhBuildStats)]
     L.cray_host_scene_flat.restype = C.POINTER(FlatScene)
     L.cray_host_scene_flat.argtypes = [C.c_void_p]
     L.cray_host_scene_build_seconds.restype = C.c_double
@@ -125,13 +137,21 @@ class HostScene:
 
     SAH, MEDIAN = 1, 0
 
-    def __init__(self, scene, split_method=1):
+    def __init__(self, scene, split_method=1, bvh_ctx=None):
+        """bvh_ctx: a Context whose GPU runs Bvh::new (cray_bvh_build_sah, same tree); None = host build."""
         self.scene = scene  # keeps the description arrays alive (the flat view borrows them)
         h = C.c_void_p()
-        _check(lib().cray_host_scene_new(C.addressof(scene.desc()), split_method, C.byref(h)), 'cray_host_scene_new')
+        if bvh_ctx is None:
+            _check(lib().cray_host_scene_new(C.addressof(scene.desc()), split_method, C.byref(h)), 'cray_host_scene_new')
+        else:
+            _check(lib().cray_host_scene_new_on(C.addressof(scene.desc()), split_method, bvh_ctx._h, C.byref(h)),
+                   'cray_host_scene_new_on')
         self._h = h
         self.flat = lib().cray_host_scene_flat(h).contents
         self.build_seconds = lib().cray_host_scene_build_seconds(h)
+        g = BvhBuildStats()
+        self.bvh_seconds = lib().cray_host_scene_bvh_seconds(h, C.byref(g))
+        self.gpu_build = {k: getattr(g, k) for k, _ in BvhBuildStats._fields_}
 
     def bvh(self):
         n, m = self.flat.n_nodes, self.flat.n_prim_refs
@@ -174,6 +194,18 @@ class Context:
 
     def upload(self, host_scene):
         return DeviceScene(self, host_scene)
+
+    def build_bvh(self, prim_bounds):
+        """Bvh::new(.., SplitMethod::SAH) on this GPU: prim_bounds [n, 6] f64 -> (nodes, prim_refs, stats)."""
+        pb = np.ascontiguousarray(prim_bounds, dtype=np.float64).reshape(-1, 6)
+        n = len(pb)
+        nodes = np.zeros(max(1, 2 * n - 1), dtype=BVH_NODE_DT)
+        refs = np.zeros(n, dtype=np.uint32)
+        n_nodes = C.c_uint32(0)
+        st = BvhBuildStats()
+        _check(lib().cray_bvh_build_sah(self._h, pb.ctypes.data, n, nodes.ctypes.data, len(nodes), C.byref(n_nodes),
+                                        refs.ctypes.data, C.byref(st)), 'cray_bvh_build_sah')
+        return nodes[:n_nodes.value], refs, {k: getattr(st, k) for k, _ in BvhBuildStats._fields_}
 
     def close(self):
         if self._h:

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <vector>
 
+#include "cray_bvh_build.h"
 #include "cray_kernels.h"
 #include "sobol_rev_vectors.h"
 
@@ -676,6 +677,140 @@ extern "C" int cray_trace(cray_ctx* c, cray_scene* s, const cray_ray* rays, size
         Counters h;
         HIP_TRY(hipMemcpy(&h, c->counters, sizeof(h), hipMemcpyDeviceToHost));
         fill_stats(h, stats);
+    }
+    return CRAY_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Bvh::new(primitives, SplitMethod::SAH) on the device (cray_bvh_build.h): same nodes, same leaf order.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct DevMem {  // frees its allocations on every exit path
+    std::vector<void*> ptrs;
+    ~DevMem() { for (void* p : ptrs) (void)hipFree(p); }
+    template <class T> hipError_t get(T** out, size_t count) {
+        void* d = nullptr;
+        hipError_t e = hipMalloc(&d, (count ? count : 1) * sizeof(T));
+        if (e == hipSuccess) ptrs.push_back(d);
+        *out = (T*)d;
+        return e;
+    }
+};
+}  // namespace
+
+extern "C" int cray_bvh_build_sah(cray_ctx* c, const double* prim_bounds, uint32_t n, cray_bvh_node* out_nodes, uint32_t node_capacity,
+                                  uint32_t* out_n_nodes, uint32_t* out_prim_refs, cray_bvh_build_stats* stats) {
+    using namespace cray::bvhb;
+    if (!c || !prim_bounds || !out_nodes || !out_n_nodes || !out_prim_refs) { set_last_error("cray_bvh_build_sah: null argument"); return CRAY_ERR_INVALID; }
+    if (n == 0) { set_last_error("Bvh::new: no primitives"); return CRAY_ERR_BUILD; }
+    if (n >= (1u << 30)) { set_last_error("cray_bvh_build_sah: too many primitives"); return CRAY_ERR_UNSUPPORTED; }
+    for (size_t i = 0; i < (size_t)n * 6; i++)
+        if (!std::isfinite(prim_bounds[i])) { set_last_error("cray_bvh_build_sah: primitive %zu has a non-finite bound", i / 6); return CRAY_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(c->device));
+    auto t_begin = std::chrono::steady_clock::now();
+    hipStream_t st = c->stream;
+    DevMem mem;
+    double* d_box; uint32_t *d_order, *d_T, *d_tmp, *d_active[2], *d_small, *d_tile, *d_total, *d_reccnt;
+    int32_t* d_slot_of; uint8_t *d_bidx, *d_flag;
+    TopNode* d_top; SmallRec* d_pool; Slot* d_slots[2]; Ctl* d_ctl; cray_bvh_node* d_out;
+    const size_t max_active = (size_t)n / (kSmall + 1) + 2;
+    const uint32_t n_tiles = (n + kScanTile - 1) / kScanTile;
+    HIP_TRY(mem.get(&d_box, (size_t)n * 6));
+    HIP_TRY(mem.get(&d_order, n));
+    HIP_TRY(mem.get(&d_slot_of, n));
+    HIP_TRY(mem.get(&d_bidx, n));
+    HIP_TRY(mem.get(&d_flag, n));
+    HIP_TRY(mem.get(&d_T, (size_t)n + 1));
+    HIP_TRY(mem.get(&d_tmp, n));
+    HIP_TRY(mem.get(&d_tile, n_tiles));
+    HIP_TRY(mem.get(&d_total, 1));
+    HIP_TRY(mem.get(&d_active[0], max_active));
+    HIP_TRY(mem.get(&d_active[1], max_active));
+    HIP_TRY(mem.get(&d_slots[0], max_active));
+    HIP_TRY(mem.get(&d_slots[1], max_active));
+    HIP_TRY(mem.get(&d_small, n));
+    HIP_TRY(mem.get(&d_reccnt, n));
+    HIP_TRY(mem.get(&d_top, (size_t)2 * n));
+    HIP_TRY(mem.get(&d_pool, (size_t)2 * n));
+    HIP_TRY(mem.get(&d_ctl, 1));
+    HIP_TRY(mem.get(&d_out, (size_t)2 * n));
+    HIP_TRY(hipMemcpyAsync(d_box, prim_bounds, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice, st));
+    hipEvent_t ev0, ev1;
+    HIP_TRY(hipEventCreate(&ev0));
+    HIP_TRY(hipEventCreate(&ev1));
+    HIP_TRY(hipEventRecord(ev0, st));
+
+    const dim3 blk(kTB), grid_n((n + kTB - 1) / kTB);
+    hipLaunchKernelGGL(k_init, grid_n, blk, 0, st, d_order, d_slot_of, n, n > kSmall ? 0 : -1);
+    hipLaunchKernelGGL(k_root, dim3(1), dim3(1), 0, st, d_top, d_slots[0], d_active[0], d_small, d_ctl, n);
+    uint32_t n_active = n > kSmall ? 1u : 0u, levels = 0;
+    Ctl h{};
+    int cur = 0;
+    int rc = CRAY_OK;
+    while (n_active > 0) {
+        if (++levels > 4096) { set_last_error("cray_bvh_build_sah: tree deeper than 4096 levels above the %u-primitive subtrees", kSmall); rc = CRAY_ERR_UNSUPPORTED; break; }
+        const dim3 grid_a((n_active + kTB - 1) / kTB);
+        hipLaunchKernelGGL(k_bounds, grid_n, blk, 0, st, d_box, d_order, d_slot_of, d_slots[cur], n);
+        hipLaunchKernelGGL(k_setup, grid_a, blk, 0, st, d_top, d_slots[cur], n_active, d_ctl);
+        hipLaunchKernelGGL(k_buckets, grid_n, blk, 0, st, d_box, d_order, d_slot_of, d_slots[cur], d_bidx, n);
+        hipLaunchKernelGGL(k_choose, grid_a, blk, 0, st, d_slots[cur], n_active, d_ctl);
+        hipLaunchKernelGGL(k_flags, grid_n, blk, 0, st, d_slot_of, d_slots[cur], d_bidx, d_flag, n);
+        hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles), blk, 0, st, d_flag, d_T, d_tile, n);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), blk, 0, st, d_tile, n_tiles, d_total);
+        hipLaunchKernelGGL(k_scan_add, grid_n, blk, 0, st, d_T, d_tile, d_total, n);
+        hipLaunchKernelGGL(k_pairs, grid_n, blk, 0, st, d_slot_of, d_slots[cur], d_top, d_flag, d_T, d_tmp, n);
+        hipLaunchKernelGGL(k_swap, grid_n, blk, 0, st, d_slot_of, d_slots[cur], d_top, d_flag, d_T, d_tmp, d_order, d_bidx, n);
+        hipLaunchKernelGGL(k_children, grid_a, blk, 0, st, d_top, d_slots[cur], d_slots[cur ^ 1], n_active, d_T, d_active[cur ^ 1], d_small, d_ctl);
+        hipLaunchKernelGGL(k_reslot, grid_n, blk, 0, st, d_slot_of, d_slots[cur], d_top, n);
+        HIP_TRY(hipMemcpyAsync(&h, d_ctl, sizeof(h), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (h.error) break;
+        n_active = h.n_next;
+        if (n_active > max_active) { set_last_error("cray_bvh_build_sah: internal error (active list overflow)"); rc = CRAY_ERR_INVALID; break; }
+        const unsigned int zero = 0;
+        HIP_TRY(hipMemcpyAsync(&d_ctl->n_next, &zero, sizeof(zero), hipMemcpyHostToDevice, st));
+        cur ^= 1;
+    }
+    if (rc == CRAY_OK && !h.error) {
+        HIP_TRY(hipMemcpyAsync(&h, d_ctl, sizeof(h), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemsetAsync(d_flag, 0, n, st));
+        hipLaunchKernelGGL(k_small, dim3((h.n_small + 63) / 64), dim3(64), 0, st, d_box, d_order, d_top, d_small, h.n_small, d_pool, d_reccnt, d_flag, d_ctl);
+        hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles), blk, 0, st, d_flag, d_T, d_tile, n);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), blk, 0, st, d_tile, n_tiles, d_total);
+        hipLaunchKernelGGL(k_scan_add, grid_n, blk, 0, st, d_T, d_tile, d_total, n);
+        hipLaunchKernelGGL(k_emit_top, dim3((h.n_top + kTB - 1) / kTB), blk, 0, st, d_top, h.n_top, d_T, d_out);
+        hipLaunchKernelGGL(k_emit_small, dim3((h.n_small + kTB - 1) / kTB), blk, 0, st, d_top, d_small, h.n_small, d_pool, d_reccnt, d_T, d_out);
+        HIP_TRY(hipEventRecord(ev1, st));
+        uint32_t n_leaves = 0;
+        Ctl h2{};
+        HIP_TRY(hipMemcpyAsync(&n_leaves, d_T + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&h2, d_ctl, sizeof(h2), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        h.error = h2.error;
+        if (!h.error) {
+            const uint32_t n_nodes = 2 * n_leaves - 1;
+            if (n_nodes > node_capacity) { set_last_error("cray_bvh_build_sah: %u nodes do not fit the caller's %u", n_nodes, node_capacity); rc = CRAY_ERR_INVALID; }
+            else {
+                float ms = 0.f;
+                HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+                HIP_TRY(hipMemcpy(out_nodes, d_out, (size_t)n_nodes * sizeof(cray_bvh_node), hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(out_prim_refs, d_order, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                *out_n_nodes = n_nodes;
+                if (stats) {
+                    stats->device_seconds = ms * 1e-3;
+                    stats->total_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+                    stats->levels = levels; stats->top_nodes = h.n_top; stats->small_subtrees = h.n_small; stats->leaves = n_leaves;
+                }
+            }
+        }
+    }
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    if (rc != CRAY_OK) return rc;
+    if (h.error) {
+        set_last_error("Bvh::new would panic in the reference (code %u: 1 zero surface area, 2 non-finite cost, 3 empty partition)", h.error);
+        return CRAY_ERR_BUILD;
     }
     return CRAY_OK;
 }

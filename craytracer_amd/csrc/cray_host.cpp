@@ -306,11 +306,18 @@ struct cray_host_scene {
     std::vector<double> cdf;
     std::vector<int32_t> first_equal;
     double build_seconds;
+    double bvh_seconds = 0.0;
+    cray_bvh_build_stats gpu_build{};
 };
 
 extern "C" int cray_host_scene_new(const cray_scene_desc* d, int split_method, cray_host_scene** out) {
+    return cray_host_scene_new_on(d, split_method, nullptr, out);
+}
+
+extern "C" int cray_host_scene_new_on(const cray_scene_desc* d, int split_method, cray_ctx* bvh_ctx, cray_host_scene** out) {
     using namespace cray;
     if (!d || !out) { set_last_error("cray_host_scene_new: null argument"); return CRAY_ERR_INVALID; }
+    if (bvh_ctx && split_method != CRAY_SPLIT_SAH) { set_last_error("the GPU builder implements SplitMethod::SAH only"); return CRAY_ERR_UNSUPPORTED; }
     *out = nullptr;
     if (d->n_lights == 0) { set_last_error("No lights in the scene."); return CRAY_ERR_INVALID; }
     if (d->n_prims == 0) { set_last_error("Bvh::new: no primitives"); return CRAY_ERR_BUILD; }
@@ -378,20 +385,39 @@ extern "C" int cray_host_scene_new(const cray_scene_desc* d, int split_method, c
         items[i].box = b;
         items[i].centroid = mk((b.lo.x + b.hi.x) * 0.5, (b.lo.y + b.hi.y) * 0.5, (b.lo.z + b.hi.z) * 0.5);
     }
-    Builder bld;
-    bld.nodes.reserve((size_t)d->n_prims * 2);
-    bld.refs.reserve(d->n_prims);
-    if (split_method == CRAY_SPLIT_MEDIAN) bld.median(items.data(), items.size());
-    else bld.sah(items.data(), items.size());
-    if (bld.error) {
-        set_last_error("Bvh::new would panic in the reference (code %d: 1 zero surface area, 2 non-finite cost, 3 empty partition)", bld.error);
-        delete hs;
-        return CRAY_ERR_BUILD;
-    }
     box3 world = items[0].box;
     for (size_t i = 1; i < items.size(); i++) world = join(world, items[i].box);
-    hs->nodes.swap(bld.nodes);
-    hs->refs.swap(bld.refs);
+    auto t_bvh = std::chrono::steady_clock::now();
+    if (bvh_ctx) {
+        // Bvh::new on the GPU (cray_bvh_build_sah, cray.h): same tree as Builder::sah below
+        std::vector<double> pb((size_t)d->n_prims * 6);
+        for (uint32_t i = 0; i < d->n_prims; i++) {
+            const box3& b = items[i].box;
+            double* o = &pb[(size_t)i * 6];
+            o[0] = b.lo.x; o[1] = b.lo.y; o[2] = b.lo.z; o[3] = b.hi.x; o[4] = b.hi.y; o[5] = b.hi.z;
+        }
+        hs->nodes.resize((size_t)d->n_prims * 2 - 1);
+        hs->refs.resize(d->n_prims);
+        uint32_t n_nodes = 0;
+        int rc = cray_bvh_build_sah(bvh_ctx, pb.data(), d->n_prims, hs->nodes.data(), (uint32_t)hs->nodes.size(), &n_nodes,
+                                    hs->refs.data(), &hs->gpu_build);
+        if (rc != CRAY_OK) { delete hs; return rc; }
+        hs->nodes.resize(n_nodes);
+    } else {
+        Builder bld;
+        bld.nodes.reserve((size_t)d->n_prims * 2);
+        bld.refs.reserve(d->n_prims);
+        if (split_method == CRAY_SPLIT_MEDIAN) bld.median(items.data(), items.size());
+        else bld.sah(items.data(), items.size());
+        if (bld.error) {
+            set_last_error("Bvh::new would panic in the reference (code %d: 1 zero surface area, 2 non-finite cost, 3 empty partition)", bld.error);
+            delete hs;
+            return CRAY_ERR_BUILD;
+        }
+        hs->nodes.swap(bld.nodes);
+        hs->refs.swap(bld.refs);
+    }
+    hs->bvh_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_bvh).count();
 
     // --- LightSampler::new (light.rs:187-200) with Light::power (:170-177), world_radius (scene.rs:42)
     double world_radius = len(world.hi - world.lo) * 0.5;
@@ -499,6 +525,11 @@ extern "C" int cray_host_scene_new(const cray_scene_desc* d, int split_method, c
 
 extern "C" const cray_flat_scene* cray_host_scene_flat(const cray_host_scene* s) { return s ? &s->flat : nullptr; }
 extern "C" double cray_host_scene_build_seconds(const cray_host_scene* s) { return s ? s->build_seconds : 0.0; }
+extern "C" double cray_host_scene_bvh_seconds(const cray_host_scene* s, cray_bvh_build_stats* gpu) {
+    if (!s) return 0.0;
+    if (gpu) *gpu = s->gpu_build;
+    return s->bvh_seconds;
+}
 extern "C" void cray_host_scene_free(cray_host_scene* s) { delete s; }
 
 extern "C" void cray_host_sincos(double x, double* s, double* c) {

@@ -154,6 +154,21 @@ int cray_render_samples(cray_ctx* ctx, cray_scene* scene, const cray_render_para
 int cray_trace(cray_ctx* ctx, cray_scene* scene, const cray_ray* rays, size_t n, cray_hit* hits, int any_hit,
                cray_stats* stats);
 
+/* Replaces Bvh::new(primitives, SplitMethod::SAH) (src/bvh.rs:38-56, 234-336) — the scene-load step that
+ * takes seconds on the host for millions of triangles — with a build on the GPU that yields the SAME tree:
+ * node bounds, split axes, topology and the order of primitives inside the leaves (util::partition_by,
+ * src/util.rs:4-26) are those of the reference's sequential recursion.
+ *   prim_bounds: n x 6 doubles (Bounds.min xyz, Bounds.max xyz of primitive i, shape.rs:402-438)
+ *   out_nodes:   DFS pre-order, at most 2n-1 (node_capacity entries provided by the caller)
+ *   out_prim_refs: n primitive indices in leaf order (cray_flat_scene.prim_refs) */
+typedef struct {
+    double device_seconds;  /* first kernel -> last kernel (HIP events) */
+    double total_seconds;   /* including allocation and the copies in and out */
+    uint32_t levels, top_nodes, small_subtrees, leaves;
+} cray_bvh_build_stats;
+int cray_bvh_build_sah(cray_ctx* ctx, const double* prim_bounds, uint32_t n, cray_bvh_node* out_nodes, uint32_t node_capacity,
+                       uint32_t* out_n_nodes, uint32_t* out_prim_refs, cray_bvh_build_stats* stats);
+
 const char* cray_last_error(void);
 
 #ifdef __cplusplus

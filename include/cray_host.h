@@ -28,10 +28,15 @@ typedef struct cray_host_scene cray_host_scene;
  * area, empty side after partition, no primitives); CRAY_ERR_INVALID for "No lights in
  * the scene." (scene_parser.rs:1104-1109) and bad indices. */
 int cray_host_scene_new(const cray_scene_desc* desc, int split_method, cray_host_scene** out);
+/* Same, with Bvh::new running on the GPU of `bvh_ctx` (cray_bvh_build_sah, cray.h; SAH only). The tree is
+ * the one cray_host_scene_new builds; NULL = build on the host. */
+int cray_host_scene_new_on(const cray_scene_desc* desc, int split_method, cray_ctx* bvh_ctx, cray_host_scene** out);
 /* The flat view stays valid until cray_host_scene_free; it borrows the desc's
  * material/texture/image/triangle arrays, which must outlive it too. */
 const cray_flat_scene* cray_host_scene_flat(const cray_host_scene* scene);
 double cray_host_scene_build_seconds(const cray_host_scene* scene);
+/* Time spent in Bvh::new alone; `gpu` (optional) receives the GPU builder's figures (zeros for a host build). */
+double cray_host_scene_bvh_seconds(const cray_host_scene* scene, cray_bvh_build_stats* gpu);
 void cray_host_scene_free(cray_host_scene* scene);
 
 /* The correctly rounded sin/cos the kernels use in sample_disk / sample_sphere
