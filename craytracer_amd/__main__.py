@@ -3,8 +3,8 @@
 
     python -m craytracer_amd --scene scenes/simple.cry --output out.pfm --width 256 --height 256 --spp 16 --max-depth 4
 
-Output: PFM (linear f32 RGB, the un-tonemapped buffer the reference hands to its EXR writer,
-craytracer.rs:366-370) or .npy.  The EXR writer and the preview window are out of scope.
+Output by extension like the reference's `image_buffer.save` (craytracer.rs:366-370): .exr (default, linear
+un-clamped f32 RGB), .pfm or .npy.  The preview window is out of scope.
 """
 import argparse
 import os
@@ -24,7 +24,7 @@ def write_pfm(path, img):
 def main(argv=None):
     ap = argparse.ArgumentParser(prog='craytracer_amd')
     ap.add_argument('--scene', '-s', required=True)
-    ap.add_argument('--output', default='out.pfm')
+    ap.add_argument('--output', default='out.exr')  # craytracer.rs:326-327
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--width', type=int, default=0)
     ap.add_argument('--height', type=int, default=0)
@@ -51,8 +51,10 @@ def main(argv=None):
     print('Rendering finished in %.3fs (%.1f Mray/s)' % (st['seconds'], (st['closest_rays'] + st['shadow_rays'] - st['shadow_skipped']) / st['seconds'] / 1e6), file=sys.stderr)
     if args.output.endswith('.npy'):
         np.save(args.output, film)
-    else:
+    elif args.output.endswith('.pfm'):
         write_pfm(args.output, film)
+    else:
+        backend.write_exr(args.output, film)
     print('Output written to %s' % args.output, file=sys.stderr)
     return 0
 

@@ -75,7 +75,7 @@ ABI_SYMBOLS = ['cray_ctx_create', 'cray_ctx_destroy', 'cray_scene_upload', 'cray
                'cray_scene_device_bytes', 'cray_render', 'cray_render_params_default', 'cray_render_samples',
                'cray_trace', 'cray_last_error', 'cray_host_scene_new', 'cray_host_scene_flat',
                'cray_host_scene_build_seconds', 'cray_host_scene_free', 'cray_host_scene_new_on',
-               'cray_host_scene_bvh_seconds', 'cray_bvh_build_sah', 'cray_host_sincos', 'cray_host_div_fast_mismatches',
+               'cray_host_scene_bvh_seconds', 'cray_bvh_build_sah', 'cray_write_exr', 'cray_read_exr', 'cray_host_sincos', 'cray_host_div_fast_mismatches',
                'cray_cry_tokenize', 'cray_cry_free_tokens', 'cray_cry_parse_value', 'cray_cry_free_string',
                'cray_cry_parse_scene', 'cray_owned_scene_desc', 'cray_owned_scene_warnings', 'cray_owned_scene_free']
 
@@ -115,6 +115,8 @@ def lib():
     L.cray_host_scene_bvh_seconds.argtypes = [C.c_void_p, C.POINTER(BvhBuildStats)]
     L.cray_bvh_build_sah.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32),
                                      C.c_void_p, C.POINTER(BvhBuildStats)]
+    L.cray_write_exr.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.cray_read_exr.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_uint64]
     L.cray_host_scene_flat.restype = C.POINTER(FlatScene)
     L.cray_host_scene_flat.argtypes = [C.c_void_p]
     L.cray_host_scene_build_seconds.restype = C.c_double
@@ -281,3 +283,18 @@ class DeviceScene:
             self.close()
         except Exception:
             pass
+
+
+def write_exr(path, film):
+    """Film [H, W, 3] f32 -> OpenEXR (cray_write_exr; the reference's `image_buffer.save`, craytracer.rs:366-370)."""
+    img = np.ascontiguousarray(film, dtype=np.float32)
+    assert img.ndim == 3 and img.shape[2] == 3
+    _check(lib().cray_write_exr(os.fsencode(path), img.shape[1], img.shape[0], img.ctypes.data), 'cray_write_exr')
+
+
+def read_exr(path):
+    w, h = C.c_uint32(0), C.c_uint32(0)
+    _check(lib().cray_read_exr(os.fsencode(path), C.byref(w), C.byref(h), None, 0), 'cray_read_exr')
+    img = np.zeros((h.value, w.value, 3), dtype=np.float32)
+    _check(lib().cray_read_exr(os.fsencode(path), C.byref(w), C.byref(h), img.ctypes.data, img.size), 'cray_read_exr')
+    return img

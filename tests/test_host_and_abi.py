@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_symbols():
     names = set()
-    for h in ('cray.h', 'cray_host.h', 'cray_cry.h'):
+    for h in sorted(f for f in os.listdir(os.path.join(ROOT, 'include')) if f.endswith('.h')):
         text = open(os.path.join(ROOT, 'include', h)).read()
         text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
         names |= set(re.findall(r'\b(cray_[a-z_0-9]+)\s*\(', text))
