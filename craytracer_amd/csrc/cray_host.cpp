@@ -542,10 +542,30 @@ extern "C" void cray_host_sincos(double x, double* s, double* c) {
 extern "C" uint64_t cray_host_div_fast_mismatches(const double* a, const double* d, uint64_t n) {
     uint64_t bad = 0;
     for (uint64_t i = 0; i < n; i++) {
-        if (!cray::div_fast_ok(d[i]) || !cray::div_range_ok(a[i])) continue;
+        const double aa = fabs(a[i]);
+        if (!cray::div_fast_ok(d[i]) || !(a[i] == 0.0 || (aa >= 0x1p-553 && aa <= 0x1p501))) continue;  // a = bound - origin
         const double y = 1.0 / d[i];
         const double q = cray::div_fast(a[i], d[i], y), ref = a[i] / d[i];
         if (memcmp(&q, &ref, 8) != 0 && !(q == 0.0 && ref == 0.0)) bad++;  // the sign of a zero quotient is immaterial to the slab test
     }
+    return bad;
+}
+
+extern "C" uint64_t cray_host_child_key_mismatches(const double* lo, const double* hi, const double* o, const double* d, uint64_t n,
+                                                   uint64_t* n_checked) {
+    using namespace cray;
+    uint64_t bad = 0, checked = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        const double *l = lo + 3 * i, *h = hi + 3 * i, *oo = o + 3 * i, *dd = d + 3 * i;
+        bool ok = true;
+        for (int k = 0; k < 3; k++) ok = ok && div_fast_ok(dd[k]) && div_range_ok(oo[k]) && div_range_ok(l[k]) && div_range_ok(h[k]) && l[k] <= h[k];
+        if (!ok) continue;
+        checked++;
+        const vec3 ov = mk(oo[0], oo[1], oo[2]), dv = mk(dd[0], dd[1], dd[2]);
+        const vec3 rd = mk(1.0 / dd[0], 1.0 / dd[1], 1.0 / dd[2]);
+        const double a = child_key(l, h, ov, dv), b = child_key_fast(l, h, ov, dv, rd);
+        if (memcmp(&a, &b, 8) != 0) bad++;
+    }
+    if (n_checked) *n_checked = checked;
     return bad;
 }

@@ -18,59 +18,8 @@ namespace cray {
 
 constexpr int kBlock = 256;
 
-// ---------------------------------------------------------------------------------
-// Slab test of one child box, split into its ray.tmax-independent part.
-// Bounds::intersects (bounds.rs:62-88) returns
-//     ok && (in(tmin) || in(tmax)),  in(t) = t > EPS && t < ray.tmax
-// where ok = no early-out fired.  tmin/tmax/ok do not depend on ray.tmax, so a child is
-// summarised by one key:  accepted  <=>  key < ray.tmax
-//     key = -inf                      if Bounds::contains(origin)        (bvh.rs:70)
-//         = +inf                      if an early-out fired
-//         = min(tmin if > EPS else +inf, tmax if > EPS else +inf)        otherwise.
-// The far child is re-checked against the *shrunken* ray.tmax when it is popped, exactly
-// when the reference tests it.  The sequential early-outs equal one final test because
-// tmax only decreases and tmin only increases over the three axes.
-// ---------------------------------------------------------------------------------
-__device__ __forceinline__ double child_key(const double* __restrict__ lo, const double* __restrict__ hi, vec3 o, vec3 d) {
-    double tmin = -inf64(), tmax = inf64();
-#pragma unroll
-    for (int ax = 0; ax < 3; ax++) {
-        double d_i = ax == 0 ? d.x : (ax == 1 ? d.y : d.z);
-        double o_i = ax == 0 ? o.x : (ax == 1 ? o.y : o.z);
-        double mn = lo[ax], mx = hi[ax];
-        if (sign_neg(d_i)) { double t = mn; mn = mx; mx = t; }
-        tmax = min_nn(tmax, (mx - o_i) / d_i);
-        tmin = max_nn(tmin, (mn - o_i) / d_i);
-    }
-    bool ok = !(tmax < kEps) && !(tmin > tmax);
-    bool inside = lo[0] <= o.x && lo[1] <= o.y && lo[2] <= o.z && hi[0] >= o.x && hi[1] >= o.y && hi[2] >= o.z;
-    double a = tmin > kEps ? tmin : inf64();
-    double b = tmax > kEps ? tmax : inf64();
-    double key = ok ? min_nn(a, b) : inf64();
-    return inside ? -inf64() : key;
-}
-
-// child_key with the six divisions replaced by the exact FMA sequence of cray_math.h (div_fast):
-// identical bits, about half the VALU instructions.  rd = 1/d per axis, computed once per ray.
-__device__ __forceinline__ double child_key_fast(const double* __restrict__ lo, const double* __restrict__ hi, vec3 o, vec3 d, vec3 rd) {
-    double tmin = -inf64(), tmax = inf64();
-#pragma unroll
-    for (int ax = 0; ax < 3; ax++) {
-        double d_i = ax == 0 ? d.x : (ax == 1 ? d.y : d.z);
-        double o_i = ax == 0 ? o.x : (ax == 1 ? o.y : o.z);
-        double y_i = ax == 0 ? rd.x : (ax == 1 ? rd.y : rd.z);
-        double mn = lo[ax], mx = hi[ax];
-        if (sign_neg(d_i)) { double t = mn; mn = mx; mx = t; }
-        tmax = min_nn(tmax, div_fast(mx - o_i, d_i, y_i));
-        tmin = max_nn(tmin, div_fast(mn - o_i, d_i, y_i));
-    }
-    bool ok = !(tmax < kEps) && !(tmin > tmax);
-    bool inside = lo[0] <= o.x && lo[1] <= o.y && lo[2] <= o.z && hi[0] >= o.x && hi[1] >= o.y && hi[2] >= o.z;
-    double a = tmin > kEps ? tmin : inf64();
-    double b = tmax > kEps ? tmax : inf64();
-    double key = ok ? min_nn(a, b) : inf64();
-    return inside ? -inf64() : key;
-}
+// child_key / child_key_fast (the slab test of one child box, split into its ray.tmax-independent part) live in
+// cray_math.h so that the host can test them against each other.
 
 // ---------------------------------------------------------------------------------
 // Scene::intersect / Scene::intersects over a queue of paths — persistent wavefront tracer.

@@ -152,8 +152,10 @@ CRAY_HD ray_t xf_ray(const double* m, const ray_t& r) {  // :456-462
 //     q0 = RN(a*y)                         (within 2 ulp of a/d)
 //     q1 = RN(q0 + (a - q0*d) * y)         (faithful: within 1 ulp; the residual is exact in an FMA)
 //     q2 = RN(q1 + (a - q1*d) * y)         (= RN(a/d) by Markstein's theorem: y correctly rounded, q1 faithful)
-// valid when nothing over/underflows: the caller guarantees that a and d are zero or within
-// [2^-500, 2^500] in magnitude and d != 0 (div_fast_ok / scene check); otherwise it divides plainly.
+// valid when nothing over/underflows: the caller guarantees that the bounds and the ray origin are zero or
+// within [2^-500, 2^500] in magnitude (div_range_ok, so a = bound - origin is 0 or >= 2^-553) and that
+// 2^-500 <= |d| <= 2^100 (div_fast_ok): every quotient is then a normal number with the sign of a, or an
+// exact zero for a == 0.  Otherwise the kernel divides plainly.
 // tests/test_host_and_abi.py checks q2 == a/d bit for bit on random and adversarial operands.
 // -----------------------------------------------------------------------------------------
 namespace cray {
@@ -161,7 +163,7 @@ CRAY_HD bool div_range_ok(double x) {  // 0 or 2^-500 <= |x| <= 2^500
     const double ax = fabs(x);
     return x == 0.0 || (ax >= 0x1p-500 && ax <= 0x1p500);
 }
-CRAY_HD bool div_fast_ok(double d) { return d != 0.0 && div_range_ok(d); }
+CRAY_HD bool div_fast_ok(double d) { const double ad = fabs(d); return ad >= 0x1p-500 && ad <= 0x1p100; }
 CRAY_HD double div_fast(double a, double d, double y) {
     const double q0 = a * y;
     const double q1 = fma(fma(-q0, d, a), y, q0);
@@ -169,6 +171,63 @@ CRAY_HD double div_fast(double a, double d, double y) {
 }
 }  // namespace cray
 
+
+namespace cray {
+// ---------------------------------------------------------------------------------
+// Slab test of one child box, split into its ray.tmax-independent part.
+// Bounds::intersects (bounds.rs:62-88) returns
+//     ok && (in(tmin) || in(tmax)),  in(t) = t > EPS && t < ray.tmax
+// where ok = no early-out fired.  tmin/tmax/ok do not depend on ray.tmax, so a child is
+// summarised by one key:  accepted  <=>  key < ray.tmax
+//     key = -inf                      if Bounds::contains(origin)        (bvh.rs:70)
+//         = +inf                      if an early-out fired
+//         = min(tmin if > EPS else +inf, tmax if > EPS else +inf)        otherwise.
+// The far child is re-checked against the *shrunken* ray.tmax when it is popped, exactly
+// when the reference tests it.  The sequential early-outs equal one final test because
+// tmax only decreases and tmin only increases over the three axes.
+// ---------------------------------------------------------------------------------
+CRAY_HD double child_key(const double* __restrict__ lo, const double* __restrict__ hi, vec3 o, vec3 d) {
+    double tmin = -inf64(), tmax = inf64();
+#pragma unroll
+    for (int ax = 0; ax < 3; ax++) {
+        double d_i = ax == 0 ? d.x : (ax == 1 ? d.y : d.z);
+        double o_i = ax == 0 ? o.x : (ax == 1 ? o.y : o.z);
+        double mn = lo[ax], mx = hi[ax];
+        if (sign_neg(d_i)) { double t = mn; mn = mx; mx = t; }
+        tmax = min_nn(tmax, (mx - o_i) / d_i);
+        tmin = max_nn(tmin, (mn - o_i) / d_i);
+    }
+    bool ok = !(tmax < kEps) && !(tmin > tmax);
+    bool inside = lo[0] <= o.x && lo[1] <= o.y && lo[2] <= o.z && hi[0] >= o.x && hi[1] >= o.y && hi[2] >= o.z;
+    double a = tmin > kEps ? tmin : inf64();
+    double b = tmax > kEps ? tmax : inf64();
+    double key = ok ? min_nn(a, b) : inf64();
+    return inside ? -inf64() : key;
+}
+
+// child_key for rays and scenes inside div_fast's guarded range (cray_math.h): identical result, ~60 instead of
+// ~110 VALU instructions.
+//  * the six divisions are the exact FMA sequence div_fast (rd = 1/d per axis, once per ray);
+//  * in that range every quotient is finite, non-NaN and has the sign of its numerator (zero only for a zero
+//    numerator: nothing underflows), so
+//      - swapping (min,max) by the sign of d and then dividing equals min/max of the two quotients
+//        (division by a fixed d is monotone under correct rounding);
+//      - Bounds::contains(origin) (lo <= o <= hi on every axis) is  tmin <= 0 <= tmax;
+//      - the early-outs / in-range selection collapse to the three comparisons below.
+CRAY_HD double child_key_fast(const double* __restrict__ lo, const double* __restrict__ hi, vec3 o, vec3 d, vec3 rd) {
+    const double ax0 = div_fast(lo[0] - o.x, d.x, rd.x), bx0 = div_fast(hi[0] - o.x, d.x, rd.x);
+    const double ax1 = div_fast(lo[1] - o.y, d.y, rd.y), bx1 = div_fast(hi[1] - o.y, d.y, rd.y);
+    const double ax2 = div_fast(lo[2] - o.z, d.z, rd.z), bx2 = div_fast(hi[2] - o.z, d.z, rd.z);
+    const double tmin = fmax(fmax(fmin(ax0, bx0), fmin(ax1, bx1)), fmin(ax2, bx2));
+    const double tmax = fmin(fmin(fmax(ax0, bx0), fmax(ax1, bx1)), fmax(ax2, bx2));
+    const bool inside = tmin <= 0.0 && tmax >= 0.0;
+    double key = tmax > kEps ? tmax : inf64();
+    key = tmin > kEps ? tmin : key;
+    key = tmin > tmax ? inf64() : key;
+    return inside ? -inf64() : key;
+}
+
+}  // namespace cray
 
 // -----------------------------------------------------------------------------------------
 // Correctly rounded sin / cos for the sampling routines (sample_disk, sample_sphere).

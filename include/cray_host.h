@@ -48,6 +48,12 @@ void cray_host_sincos(double x, double* sin_out, double* cos_out);
  * bitwise, among the pairs that pass the range guard. */
 uint64_t cray_host_div_fast_mismatches(const double* a, const double* d, uint64_t n);
 
+/* The traversal kernel's fast slab test (cray_math.h child_key_fast) against the literal restatement of
+ * Bounds::intersects / Bounds::contains (child_key) on n boxes (lo, hi: n x 3) and rays (o, d: n x 3): returns the
+ * number of bitwise-different keys among the inputs inside the guarded range (their count in *n_checked). */
+uint64_t cray_host_child_key_mismatches(const double* lo, const double* hi, const double* o, const double* d, uint64_t n,
+                                        uint64_t* n_checked);
+
 #ifdef __cplusplus
 }
 #endif

@@ -158,3 +158,43 @@ def test_div_fast_is_the_correctly_rounded_quotient():
     for a, d in cases:
         a, d = np.ascontiguousarray(a, dtype=np.float64), np.ascontiguousarray(d, dtype=np.float64)
         assert L.cray_host_div_fast_mismatches(a.ctypes.data, d.ctypes.data, n) == 0
+
+
+def test_fast_slab_test_equals_the_literal_one():
+    """child_key_fast (min/max of exact quotients, contains() from the signs, three comparisons) must give the
+    key of the literal Bounds::intersects / contains restatement bit for bit: random boxes and rays, origins
+    exactly on faces / edges / corners and inside, flat (zero-width) boxes, tiny and axis-dominated directions,
+    boxes behind the origin, huge coordinates (the dragon scene's 1e5 ground sphere)."""
+    L = backend.lib()
+    rng = np.random.default_rng(1)
+    n = 1_000_000
+
+    def run(lo, hi, o, d):
+        arrs = [np.ascontiguousarray(x, dtype=np.float64) for x in (lo, hi, o, d)]
+        checked = C.c_uint64(0)
+        bad = L.cray_host_child_key_mismatches(*[a.ctypes.data for a in arrs], len(arrs[0]), C.byref(checked))
+        return bad, checked.value
+
+    c = rng.normal(size=(n, 3)) * 10.0 ** rng.integers(-2, 5, (n, 1))
+    half = np.abs(rng.normal(size=(n, 3))) * 10.0 ** rng.integers(-3, 3, (n, 1))
+    half[rng.random((n, 3)) < 0.05] = 0.0                       # flat boxes
+    lo, hi = c - half, c + half
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[rng.random(n) < 0.1] *= np.array([1.0, 1e-12, 1e-150])    # nearly axis-parallel
+    o = c + rng.normal(size=(n, 3)) * 10.0 ** rng.integers(-3, 4, (n, 1))
+    # origins exactly on a bound of some axes, or exactly inside
+    pick = rng.random((n, 3))
+    o = np.where(pick < 0.15, lo, np.where(pick < 0.3, hi, o))
+    inside = rng.random(n) < 0.1
+    o[inside] = (lo + (hi - lo) * rng.random((n, 3)))[inside]
+    bad, checked = run(lo, hi, o, d)
+    assert checked > 0.9 * n and bad == 0
+    # hits at distances around EPSILON = 1e-9: origin a hair in front of / behind a face
+    eps_off = 10.0 ** rng.uniform(-12, -6, (n, 1)) * rng.choice([-1.0, 1.0], (n, 1))
+    o2 = np.where(pick < 0.5, lo + eps_off, o)
+    bad, checked = run(lo, hi, o2, d)
+    assert checked > 0.9 * n and bad == 0
+    # inputs outside the guard (zero direction components) are skipped by the kernel too (plain division path)
+    d0 = d.copy(); d0[:, 0] = 0.0
+    assert run(lo, hi, o, d0)[1] == 0
