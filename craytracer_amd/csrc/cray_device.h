@@ -120,6 +120,7 @@ struct Counters {
     unsigned long long nonfinite, stack_overflow, shadow_skipped;
     unsigned int n_active[2], n_shadow, trace_head;
     unsigned int n_class[kShadeClasses];
+    unsigned long long diag[16];  // k_trace lane-occupancy diagnostics (CRAY_TRACE_DIAG builds only)
 };
 
 }  // namespace cray

@@ -172,6 +172,15 @@ void fill_stats(const Counters& h, cray_stats* st) {
     st->shadow_nodes = h.shadow_nodes; st->shadow_prims = h.shadow_prims;
     st->closest_tri_tests = h.closest_tri; st->shadow_tri_tests = h.shadow_tri;
     st->nonfinite = h.nonfinite; st->stack_overflow = h.stack_overflow;
+#ifdef CRAY_TRACE_DIAG
+    for (int a = 0; a < 2; a++) {
+        const unsigned long long* g = h.diag + 8 * a;
+        if (!g[0]) continue;
+        fprintf(stderr, "diag %s: wave-iterations %llu, active lanes/iter %.1f (interior %.1f, leaf %.1f); exhausted iters %.1f%% at %.1f lanes; refills %llu x %.1f lanes\n",
+                a ? "any" : "closest", g[0], (double)g[1] / g[0], (double)g[6] / g[0], (double)g[7] / g[0], 100.0 * g[2] / g[0],
+                g[2] ? (double)g[3] / g[2] : 0.0, g[4], g[4] ? (double)g[5] / g[4] : 0.0);
+    }
+#endif
 }
 
 }  // namespace

@@ -48,6 +48,9 @@ __global__ void __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace(DevScene sc,
     const unsigned int lane = __lane_id();
     unsigned long long n_nodes = 0, n_prims = 0, n_tri = 0;
     unsigned int overflow = 0;
+#ifdef CRAY_TRACE_DIAG
+    unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 
     // Traversal stack: the bottom kLdsStack entries of every lane live in LDS ([entry][thread], so a
     // wave's access is conflict-free), deeper entries (rare) spill to scratch.
@@ -106,6 +109,9 @@ __global__ void __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace(DevScene sc,
             const bool take = !active && rank < res_left;
             const unsigned int mine = res_base + rank;
             const unsigned int taken = (unsigned int)__popcll(__ballot(take));
+#ifdef CRAY_TRACE_DIAG
+            dg[4] += 1; dg[5] += taken;
+#endif
             res_base += taken; res_left -= taken;
             if (take) {
                 p = queue ? queue[mine] : mine;
@@ -140,6 +146,14 @@ __global__ void __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace(DevScene sc,
         }
 
         bool need_pop = false, finished = false, occluded = false;
+#ifdef CRAY_TRACE_DIAG
+        {
+            const unsigned int na = (unsigned int)__popcll(__ballot(active));
+            const unsigned int nl = (unsigned int)__popcll(__ballot(active && ref_is_leaf(cur)));
+            dg[0] += 1; dg[1] += na; dg[6] += na - nl; dg[7] += nl;
+            if (exhausted) { dg[2] += 1; dg[3] += na; }
+        }
+#endif
         // ---- one record fetch per iteration: the interior node `cur` (7 x 16 B) or the first slot of
         // the leaf `cur` (5 x 16 B) through the SAME seven load instructions, hence one memory wait per
         // iteration for the whole wave instead of one for the node and a dependent one for the leaf.
@@ -231,6 +245,10 @@ __global__ void __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace(DevScene sc,
         if (n_tri) atomicAdd(ANY ? &ctr->shadow_tri : &ctr->closest_tri, n_tri);
     }
     if (overflow) atomicAdd(&ctr->stack_overflow, 1ull);
+#ifdef CRAY_TRACE_DIAG
+    if (lane == 0)
+        for (int k = 0; k < 8; k++) atomicAdd(&ctr->diag[(ANY ? 8 : 0) + k], dg[k]);
+#endif
 #undef CRAY_PUSH
 }
 
@@ -316,7 +334,7 @@ __global__ void __launch_bounds__(kBlock) k_classify(DevScene sc, PathState ps, 
 
 // The body of one estimate_Li iteration between the two BVH queries (path_integrator.rs:56-211).
 #ifndef CRAY_SHADE_WAVES
-#define CRAY_SHADE_WAVES 1
+#define CRAY_SHADE_WAVES 2
 #endif
 __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
                                                   const unsigned int* __restrict__ n_ptr, uint32_t n_fixed, uint32_t bounce,
@@ -394,7 +412,12 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
 
                 // next-event estimation (:129-164): build the shadow ray and the term it gates
 #ifndef CRAY_EXP_NO_NEE
-                {
+                // A material without a diffuse lobe makes the gated term exactly zero: the light is not even
+                // sampled (unless traversal is being counted).  Deviation from the reference only where it
+                // would panic anyway: a non-finite Li / pdf factor times that zero (NaN) on an unoccluded ray.
+                if (!trace_all_shadow && !material_has_diffuse_lobe(sc, mat)) {
+                    skip_shadow = true;
+                } else {
                     double sel_pdf;
                     const uint32_t li = light_select(sc, sa[3], sel_pdf);
                     const DevLight& l = sc.lights[li];
@@ -440,15 +463,17 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
                     } else {
                         contrib = beta * Li * f * cos_t / sel_pdf;
                     }
-                    ps.sox[p] = x.x; ps.soy[p] = x.y; ps.soz[p] = x.z;
-                    ps.sdx[p] = w_i.x; ps.sdy[p] = w_i.y; ps.sdz[p] = w_i.z;
-                    ps.stmax[p] = s_tmax;
-                    ps.cr[p] = contrib.r; ps.cg[p] = contrib.g; ps.cb[p] = contrib.b;
                     // The reference queries Scene::intersects unconditionally (:141).  When the term it
-                    // gates is exactly zero (purely specular lobes, pdf 0, black f) the answer cannot
+                    // gates is exactly zero (pdf 0, black f, light behind the surface) the answer cannot
                     // change L (L + 0 == L), so the query is skipped unless traversal is being counted.
                     want_shadow = trace_all_shadow || !black(contrib);
                     skip_shadow = !want_shadow;
+                    if (want_shadow) {
+                        ps.sox[p] = x.x; ps.soy[p] = x.y; ps.soz[p] = x.z;
+                        ps.sdx[p] = w_i.x; ps.sdy[p] = w_i.y; ps.sdz[p] = w_i.z;
+                        ps.stmax[p] = s_tmax;
+                        ps.cr[p] = contrib.r; ps.cg[p] = contrib.g; ps.cb[p] = contrib.b;
+                    }
                 }
 #endif
 

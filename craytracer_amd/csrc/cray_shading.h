@@ -476,6 +476,19 @@ __device__ inline bool lobe_sample(const DevScene& sc, const cray_bxdf& bx, doub
 
 // material < 0 is the black matte of an AreaLightPrimitive (primitive.rs:40-46): a Lambertian lobe
 // with reflectance Constant(BLACK); kept implicit so that no table entry is needed.
+// Only Lambertian and Oren-Nayar lobes have a non-zero f() (bxdf.rs: every specular lobe returns BLACK from f and
+// 0 from pdf); the implicit material of an area light's own surface is a black Lambertian (primitive.rs:40-46).
+// For a material without such a lobe the NEE term  beta * Li * f * cos * w / pdf  is exactly (0,0,0) whenever its
+// other factors are finite.
+__device__ inline bool material_has_diffuse_lobe(const DevScene& sc, int32_t mat) {
+    if (mat < 0) return false;
+    const cray_material& m = sc.materials[mat];
+    const int nb = m.is_bsdf ? m.n_bxdfs : 1;
+    for (int i = 0; i < nb; i++)
+        if (sc.bxdfs[m.first_bxdf + i].kind <= CRAY_BXDF_OREN_NAYAR) return true;
+    return false;
+}
+
 __device__ inline rgb material_f(const DevScene& sc, int32_t mat, vec3 w_o, vec3 w_i, vec3 n, double u, double v) {
     const rgb zero = mkc(0, 0, 0);
     if (mat < 0) return same_side(n, w_o, w_i) ? zero * kInvPi : zero;
