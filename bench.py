@@ -10,8 +10,8 @@ the Film tiles over RCCL (strong scaling, as the north star defines it).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (k_trace closest hit):
-algorithmic bytes / HIP-event time of that kernel over the timed steps.  `cpu_baseline`
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel family (BVH traversal, k_trace*):
+algorithmic bytes / HIP-event time of those launches over the timed steps.  `cpu_baseline`
 is the CPU oracle (a C++ restatement of the reference path; the Rust reference cannot be built
 here) on a bounded sample of the same workload.
 """
@@ -118,7 +118,9 @@ def main():
     elapsed = time.perf_counter() - t_start
     el = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
     rays = torch.tensor([float(sum(s['closest_rays'] + s['shadow_rays'] - s['shadow_skipped'] for s in stats))], dtype=torch.float64, device='cuda')
-    kern = torch.tensor([sum(s['trace_closest_ms'] for s in stats), float(sum(s['trace_closest_launches'] for s in stats)),
+    trace_ms = sum(s['trace_closest_ms'] + s['trace_mixed_ms'] + s['trace_any_ms'] for s in stats)
+    trace_launches = sum(s['trace_closest_launches'] + s['trace_mixed_launches'] + s['trace_any_launches'] for s in stats)
+    kern = torch.tensor([trace_ms, float(trace_launches), sum(s['trace_closest_ms'] for s in stats), sum(s['trace_mixed_ms'] for s in stats),
                          sum(s['trace_any_ms'] for s in stats), sum(s['shade_ms'] for s in stats), sum(s['other_ms'] for s in stats)],
                         dtype=torch.float64, device='cuda')
     if world > 1:
@@ -127,15 +129,20 @@ def main():
     elapsed = float(el.item())
     total_rays = float(rays.item())
 
-    # --- roofline of the dominant kernel (closest-hit traversal), this rank's share of the frame
+    # --- roofline of the dominant kernel family: BVH traversal (k_trace<closest> for bounce 0, k_trace_mixed =
+    # shadow rays of bounce b + segments of bounce b+1, k_trace<any> for the last bounce), this rank's share.
+    # Algorithmic bytes come from one counting pass over the queries the timed frames actually traverse
+    # (count_traversal=2: zero-term shadow rays skipped, like in the timed frames).
     roofline = None
     counts = None
     if args.count_pass:
-        _, cst = dev.render(seed=0, rank=rank, world_size=world, out_device_ptr=film.data_ptr(), count_traversal=True)
+        _, cst = dev.render(seed=0, rank=rank, world_size=world, out_device_ptr=film.data_ptr(), count_traversal=2)
         counts = cst
-        tri = cst['closest_tri_tests']
-        other = cst['closest_prims'] - tri
-        alg_bytes_frame = B_NODE * cst['closest_nodes'] + B_TRI * tri + B_OTHER * other + B_RAY * cst['closest_rays']
+        tri = cst['closest_tri_tests'] + cst['shadow_tri_tests']
+        other = cst['closest_prims'] + cst['shadow_prims'] - tri
+        nodes = cst['closest_nodes'] + cst['shadow_nodes']
+        traced = cst['closest_rays'] + cst['shadow_rays'] - cst['shadow_skipped']
+        alg_bytes_frame = B_NODE * nodes + B_TRI * tri + B_OTHER * other + B_RAY * traced
         k_ms, k_launches = float(kern[0].item()), float(kern[1].item())
         launches_per_frame = k_launches / max(1, args.steps)
         avg_ms = k_ms / max(1.0, k_launches)
@@ -144,14 +151,14 @@ def main():
         tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(args.workload, {}).get('trace_closest_bytes_per_launch')
+                traffic = json.load(open(tpath)).get(args.workload, {}).get('trace_bytes_per_launch')
             except Exception:
                 traffic = None
-        roofline = {'bound': 'hbm', 'kernel': 'k_trace<closest>', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
+        roofline = {'bound': 'hbm', 'kernel': 'k_trace family (k_trace<closest> + k_trace_mixed + k_trace<any>)', 'achieved': round(achieved, 2),
+                    'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
                     'alg_bytes_per_launch': round(alg_bytes_frame / max(1.0, launches_per_frame)),
                     'avg_launch_ms': round(avg_ms, 4), 'launches_per_step': launches_per_frame,
-                    'bytes_per_ray': round(alg_bytes_frame / max(1, cst['closest_rays']), 1)}
+                    'bytes_per_ray': round(alg_bytes_frame / max(1, traced), 1)}
 
     # --- CPU baseline: the oracle on a bounded sample of the same workload (rank 0, N=1 only)
     cpu = None
@@ -183,11 +190,12 @@ def main():
                        'rays_per_frame': int(total_rays / args.steps),
                        'reference_queries_per_frame': int(sum(s['closest_rays'] + s['shadow_rays'] for s in stats) / args.steps) if world == 1 else None},
             'roofline': roofline, 'cpu_baseline': cpu,
-            'kernel_ms_per_step': {'trace_closest': round(float(kern[0].item()) / args.steps, 2), 'trace_any': round(float(kern[2].item()) / args.steps, 2),
-                                   'shade': round(float(kern[3].item()) / args.steps, 2), 'other': round(float(kern[4].item()) / args.steps, 2)},
+            'kernel_ms_per_step': {'trace': round(float(kern[0].item()) / args.steps, 2), 'trace_closest_bounce0': round(float(kern[2].item()) / args.steps, 2),
+                                   'trace_mixed': round(float(kern[3].item()) / args.steps, 2), 'trace_any_last_bounce': round(float(kern[4].item()) / args.steps, 2),
+                                   'shade': round(float(kern[5].item()) / args.steps, 2), 'other': round(float(kern[6].item()) / args.steps, 2)},
         }
         if counts:
-            line['traversal'] = {k: counts[k] for k in ('closest_rays', 'shadow_rays', 'closest_nodes', 'closest_prims', 'shadow_nodes', 'shadow_prims')}
+            line['traversal'] = {k: counts[k] for k in ('closest_rays', 'shadow_rays', 'shadow_skipped', 'closest_nodes', 'closest_prims', 'shadow_nodes', 'shadow_prims')}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -30,10 +30,11 @@ class Stats(C.Structure):
                 ('paths', 'closest_rays', 'shadow_rays', 'shadow_skipped', 'closest_nodes', 'closest_prims', 'shadow_nodes',
                  'shadow_prims', 'closest_tri_tests', 'shadow_tri_tests', 'nonfinite', 'stack_overflow')] + \
                [(n, C.c_double) for n in ('seconds', 'trace_closest_ms', 'trace_any_ms', 'shade_ms', 'other_ms')] + \
-               [(n, C.c_uint32) for n in ('trace_closest_launches', 'trace_any_launches', 'shade_launches', 'pad_')]
+               [(n, C.c_uint32) for n in ('trace_closest_launches', 'trace_any_launches', 'shade_launches', 'pad_')] + \
+               [('trace_mixed_ms', C.c_double), ('trace_mixed_launches', C.c_uint32), ('pad2_', C.c_uint32)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_ if n != 'pad_'}
+        return {n: getattr(self, n) for n, _ in self._fields_ if n not in ('pad_', 'pad2_')}
 
 
 RAY_DT = np.dtype([('o', '<f8', 3), ('d', '<f8', 3), ('tmax', '<f8')], align=True)
@@ -242,7 +243,7 @@ class DeviceScene:
         p.seed, p.rank, p.world_size = seed, rank, world_size
         if sample_range is not None:
             p.sample_begin, p.sample_end = sample_range
-        p.count_traversal = 1 if count_traversal else 0
+        p.count_traversal = int(count_traversal)  # True/1: every reference query; 2: only the traversed ones
         p.max_paths_in_flight = max_paths_in_flight
         return p
 

@@ -62,6 +62,7 @@ struct cray_ctx {
     uint32_t* shadow_queue = nullptr;
     uint32_t* class_queues = nullptr;  // kShadeClasses x capacity (material sort)
     int sort_shade = 0;
+    int mix_trace = 1;  // shadow rays of bounce b and segments of bounce b+1 in one launch (CRAY_MIX_TRACE=0 disables)
     Counters* counters = nullptr;
     uint32_t* pix_list = nullptr;
     size_t pix_capacity = 0;
@@ -125,6 +126,7 @@ int ensure_state(cray_ctx* c, size_t capacity) {
     return CRAY_OK;
 }
 
+enum { FAM_CLOSEST = 0, FAM_ANY = 1, FAM_SHADE = 2, FAM_OTHER = 3, FAM_MIXED = 4, FAM_COUNT = 5 };
 struct EventTimer {
     cray_ctx* c;
     size_t used = 0;
@@ -146,8 +148,8 @@ struct EventTimer {
         HIP_TRY(hipEventRecord(c->events[spans.back().b], c->stream));
         return CRAY_OK;
     }
-    int collect(double ms[4], uint32_t launches[4]) {
-        for (int i = 0; i < 4; i++) { ms[i] = 0.0; launches[i] = 0; }
+    int collect(double ms[FAM_COUNT], uint32_t launches[FAM_COUNT]) {
+        for (int i = 0; i < FAM_COUNT; i++) { ms[i] = 0.0; launches[i] = 0; }
         for (const Span& s : spans) {
             float t = 0.f;
             HIP_TRY(hipEventElapsedTime(&t, c->events[s.a], c->events[s.b]));
@@ -157,7 +159,6 @@ struct EventTimer {
         return CRAY_OK;
     }
 };
-enum { FAM_CLOSEST = 0, FAM_ANY = 1, FAM_SHADE = 2, FAM_OTHER = 3 };
 
 int grid_for(const cray_ctx* c, size_t n, int blocks_per_cu) {
     size_t want = (n + kBlock - 1) / kBlock;
@@ -205,6 +206,7 @@ extern "C" int cray_ctx_create(int device_id, void* stream, cray_ctx** out) {
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else { HIP_TRY(hipStreamCreate(&c->stream)); c->own_stream = true; }
     HIP_TRY(hipMalloc((void**)&c->counters, sizeof(Counters)));
+    if (const char* e = getenv("CRAY_MIX_TRACE")) c->mix_trace = atoi(e);
     if (const char* e = getenv("CRAY_REFILL_MIN")) c->refill_min = (unsigned int)atoi(e);
     if (const char* e = getenv("CRAY_TRACE_BLOCKS_PER_CU")) c->trace_blocks_per_cu = atoi(e);
     if (const char* e = getenv("CRAY_SHADE_BLOCKS_PER_CU")) c->shade_blocks_per_cu = atoi(e);
@@ -416,6 +418,11 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
     hipLaunchKernelGGL(k_raygen, dim3(grid_for(c, n_paths, 8)), dim3(kBlock), 0, st, d, c->ps, c->pix_list, pp.px0, n_paths, spp_pass, pp.s_lo, prm.seed);
     if (tm) { int e = tm->end(); if (e) return e; }
 
+    // Launch sequence of a pass.  The shadow rays of bounce b and the path segments of bounce b+1 both depend on
+    // k_shade(b) only, so they share ONE persistent launch (k_trace_mixed); with traversal counting (or the
+    // material sort experiment) every query kind keeps its own launch so that the counters stay per kind.
+    const bool mixed = !count && !c->sort_shade && c->mix_trace;
+    const unsigned int trace_all = prm.count_traversal == 1 ? 1u : 0u;  // 2 = count, but keep skipping zero-term shadow rays
     for (uint32_t b = 0; b < d.max_depth; b++) {
         const uint32_t* q = b == 0 ? nullptr : c->queue[b & 1];
         const unsigned int* nq = b == 0 ? nullptr : &ctr->n_active[b & 1];
@@ -425,11 +432,13 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
         const int g_trace = grid_for(c, n_paths, c->trace_blocks_per_cu);  // persistent: 4 blocks x 4 waves per CU at 4 waves/SIMD
         const int g_shade = grid_for(c, n_paths, c->shade_blocks_per_cu);
 
-        HIP_TRY(hipMemsetAsync(&ctr->trace_head, 0, sizeof(unsigned int), st));
-        if (tm) { int e = tm->begin(FAM_CLOSEST); if (e) return e; }
-        if (count) hipLaunchKernelGGL((k_trace<false, true>), dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
-        else hipLaunchKernelGGL((k_trace<false, false>), dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
-        if (tm) { int e = tm->end(); if (e) return e; }
+        if (!mixed || b == 0) {
+            HIP_TRY(hipMemsetAsync(&ctr->trace_head, 0, sizeof(unsigned int), st));
+            if (tm) { int e = tm->begin(FAM_CLOSEST); if (e) return e; }
+            if (count) hipLaunchKernelGGL((k_trace<false, true>), dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
+            else hipLaunchKernelGGL((k_trace<false, false>), dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
+            if (tm) { int e = tm->end(); if (e) return e; }
+        }
 
         HIP_TRY(hipMemsetAsync(n_next, 0, sizeof(unsigned int), st));
         HIP_TRY(hipMemsetAsync(&ctr->n_shadow, 0, sizeof(unsigned int), st));
@@ -440,17 +449,24 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
             hipLaunchKernelGGL(k_classify, dim3(grid_for(c, n_paths, 8)), dim3(kBlock), 0, st, d, c->ps, q, nq, n_paths, c->class_queues, c->capacity, ctr->n_class);
             for (int cl = 0; cl < kShadeClasses; cl++)
                 hipLaunchKernelGGL(k_shade, dim3(g_shade), dim3(kBlock), 0, st, d, c->ps, (const uint32_t*)(c->class_queues + (size_t)cl * c->capacity),
-                                   (const unsigned int*)&ctr->n_class[cl], 0u, b, spp_pass, pp.s_lo, q_next, n_next, c->shadow_queue, &ctr->n_shadow, ctr, count ? 1u : 0u);
+                                   (const unsigned int*)&ctr->n_class[cl], 0u, b, spp_pass, pp.s_lo, q_next, n_next, c->shadow_queue, &ctr->n_shadow, ctr, trace_all);
         } else {
             hipLaunchKernelGGL(k_shade, dim3(g_shade), dim3(kBlock), 0, st, d, c->ps, q, nq, n_paths, b, spp_pass, pp.s_lo, q_next, n_next,
-                               c->shadow_queue, &ctr->n_shadow, ctr, count ? 1u : 0u);
+                               c->shadow_queue, &ctr->n_shadow, ctr, trace_all);
         }
         if (tm) { int e = tm->end(); if (e) return e; }
 
-        if (tm) { int e = tm->begin(FAM_ANY); if (e) return e; }
-        if (count) hipLaunchKernelGGL((k_trace<true, true>), dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, c->shadow_queue, &ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
-        else hipLaunchKernelGGL((k_trace<true, false>), dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, c->shadow_queue, &ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
-        if (tm) { int e = tm->end(); if (e) return e; }
+        if (mixed && b + 1 < d.max_depth) {
+            if (tm) { int e = tm->begin(FAM_MIXED); if (e) return e; }
+            hipLaunchKernelGGL(k_trace_mixed, dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow,
+                               (const uint32_t*)q_next, (const unsigned int*)n_next, ctr, &ctr->trace_head, c->refill_min);
+            if (tm) { int e = tm->end(); if (e) return e; }
+        } else {
+            if (tm) { int e = tm->begin(FAM_ANY); if (e) return e; }
+            if (count) hipLaunchKernelGGL((k_trace<true, true>), dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, c->shadow_queue, &ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
+            else hipLaunchKernelGGL((k_trace<true, false>), dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, c->shadow_queue, &ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
+            if (tm) { int e = tm->end(); if (e) return e; }
+        }
     }
     if (tm) { int e = tm->begin(FAM_OTHER); if (e) return e; }
     {
@@ -572,8 +588,9 @@ extern "C" int cray_render(cray_ctx* c, cray_scene* s, const cray_render_params*
         fill_stats(h, stats);
         stats->paths = need;
         stats->seconds = std::chrono::duration<double>(t1 - t0).count();
-        double ms[4]; uint32_t launches[4];
+        double ms[FAM_COUNT]; uint32_t launches[FAM_COUNT];
         if ((e = timer.collect(ms, launches))) return e;
+        stats->trace_mixed_ms = ms[FAM_MIXED]; stats->trace_mixed_launches = launches[FAM_MIXED];
         stats->trace_closest_ms = ms[FAM_CLOSEST]; stats->trace_any_ms = ms[FAM_ANY];
         stats->shade_ms = ms[FAM_SHADE]; stats->other_ms = ms[FAM_OTHER];
         stats->trace_closest_launches = launches[FAM_CLOSEST]; stats->trace_any_launches = launches[FAM_ANY];

@@ -40,11 +40,20 @@ constexpr int kBlock = 256;
 #ifndef CRAY_TRACE_WAVES
 #define CRAY_TRACE_WAVES 4
 #endif
-template <bool ANY, bool COUNT>
-__global__ void __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace(DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
-                                                  const unsigned int* __restrict__ n_ptr, uint32_t n_fixed,
-                                                  const double* __restrict__ closest_tmax, Counters* ctr, unsigned int* work_head, unsigned int refill_min) {
-    const uint32_t n = n_ptr ? *n_ptr : n_fixed;
+//  MODE 2 (mixed): ONE launch traces the shadow rays of bounce b (positions [0, n_any) of a virtual queue) and
+//  the path segments of bounce b+1 (the rest).  The two depend only on k_shade of bounce b, not on each other
+//  (the shadow rays add to L, the segments write hit records), and together they have one drain phase instead
+//  of two — the lanes of a draining any-hit launch were 84 % idle for a fifth of its iterations.
+enum { kTraceClosest = 0, kTraceAny = 1, kTraceMixed = 2 };
+template <int MODE, bool COUNT>
+__device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& ps, const uint32_t* __restrict__ queue, const uint32_t n_first,
+                                           const uint32_t* __restrict__ queue_b, const uint32_t n_b, const double* __restrict__ closest_tmax,
+                                           Counters* ctr, unsigned int* work_head, unsigned int refill_min) {
+    static_assert(!(COUNT && MODE == kTraceMixed), "traversal counting uses the separate launches");
+    constexpr bool ANY = MODE == kTraceAny;   // for the counting code, which never runs mixed
+    const uint32_t n = n_first + n_b;
+    bool is_any = MODE == kTraceAny;          // per lane in mixed mode
+#define CRAY_ANY_LANE (MODE == kTraceMixed ? is_any : (MODE == kTraceAny))
     const unsigned int lane = __lane_id();
     unsigned long long n_nodes = 0, n_prims = 0, n_tri = 0;
     unsigned int overflow = 0;
@@ -87,7 +96,7 @@ __global__ void __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace(DevScene sc,
         // Results of finished rays stay in registers until the wave refills (or drains): the stores then
         // run once with many lanes instead of in almost every iteration with one or two.
         if ((do_refill || idle == ~0ull) && pending) {
-            if (ANY) {
+            if (CRAY_ANY_LANE) {
                 ps.lr[p] = ps.lr[p] + ps.cr[p];
                 ps.lg[p] = ps.lg[p] + ps.cg[p];
                 ps.lb[p] = ps.lb[p] + ps.cb[p];
@@ -114,8 +123,14 @@ __global__ void __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace(DevScene sc,
 #endif
             res_base += taken; res_left -= taken;
             if (take) {
-                p = queue ? queue[mine] : mine;
-                if (ANY) {
+                if (MODE == kTraceMixed) {
+                    is_any = mine < n_first;
+                    if (is_any) p = queue[mine];
+                    else p = queue_b ? queue_b[mine - n_first] : mine - n_first;
+                } else {
+                    p = queue ? queue[mine] : mine;
+                }
+                if (CRAY_ANY_LANE) {
                     ray.o = mk(ps.sox[p], ps.soy[p], ps.soz[p]);
                     ray.d = mk(ps.sdx[p], ps.sdy[p], ps.sdz[p]);
                     ray.tmax = ps.stmax[p];
@@ -207,21 +222,21 @@ __global__ void __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace(DevScene sc,
                     if (COUNT) n_tri += 1;
                     double t, u, v;
                     if (tri_test(mk(r0.x, r0.y, r1.x), mk(r1.y, r2.x, r2.y), mk(r3.x, r3.y, r4.x), ray, t, u, v)) {
-                        if (ANY) { occluded = true; break; }
+                        if (CRAY_ANY_LANE) { occluded = true; break; }
                         ray.tmax = t;  // Ray::update_max_distance
                         hit_t = t; hit_u = u; hit_v = v; hit_prim = (int32_t)s_prim;
                     }
                 } else {
                     const cray_prim& pr = sc.prims[s_prim];
-                    bool hit = s_kind == CRAY_SHAPE_SPHERE ? sphere_hit(sc.spheres[pr.shape], ray, ANY, nullptr)
-                                                         : disk_hit(sc.disks[pr.shape], ray, ANY, nullptr);
+                    bool hit = s_kind == CRAY_SHAPE_SPHERE ? sphere_hit(sc.spheres[pr.shape], ray, CRAY_ANY_LANE, nullptr)
+                                                         : disk_hit(sc.disks[pr.shape], ray, CRAY_ANY_LANE, nullptr);
                     if (hit) {
-                        if (ANY) { occluded = true; break; }
+                        if (CRAY_ANY_LANE) { occluded = true; break; }
                         hit_t = ray.tmax; hit_prim = (int32_t)s_prim;  // distance: ray.max_distance (primitive.rs:66)
                     }
                 }
             }
-            if (ANY && occluded) finished = true; else need_pop = true;
+            if (CRAY_ANY_LANE && occluded) finished = true; else need_pop = true;
         }
         // ---- pop: a deferred child is re-tested against the current (shrunken) ray.tmax
         if (active && need_pop) {
@@ -234,11 +249,18 @@ __global__ void __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace(DevScene sc,
             }
         }
         if (active && finished) {
-            pending = ANY ? !occluded : true;
+            pending = CRAY_ANY_LANE ? !occluded : true;
             active = false;
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ANY ? &ctr->shadow_rays : &ctr->closest_rays, (unsigned long long)n);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (MODE == kTraceMixed) {
+            atomicAdd(&ctr->shadow_rays, (unsigned long long)n_first);
+            atomicAdd(&ctr->closest_rays, (unsigned long long)n_b);
+        } else {
+            atomicAdd(ANY ? &ctr->shadow_rays : &ctr->closest_rays, (unsigned long long)n);
+        }
+    }
     if (COUNT) {
         if (n_nodes) atomicAdd(ANY ? &ctr->shadow_nodes : &ctr->closest_nodes, n_nodes);
         if (n_prims) atomicAdd(ANY ? &ctr->shadow_prims : &ctr->closest_prims, n_prims);
@@ -250,6 +272,22 @@ __global__ void __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace(DevScene sc,
         for (int k = 0; k < 8; k++) atomicAdd(&ctr->diag[(ANY ? 8 : 0) + k], dg[k]);
 #endif
 #undef CRAY_PUSH
+#undef CRAY_ANY_LANE
+}
+
+template <bool ANY, bool COUNT>
+__global__ void __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace(DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
+                                                  const unsigned int* __restrict__ n_ptr, uint32_t n_fixed,
+                                                  const double* __restrict__ closest_tmax, Counters* ctr, unsigned int* work_head, unsigned int refill_min) {
+    trace_body<ANY ? kTraceAny : kTraceClosest, COUNT>(sc, ps, queue, n_ptr ? *n_ptr : n_fixed, nullptr, 0u, closest_tmax, ctr, work_head, refill_min);
+}
+
+// shadow rays of one bounce (any_queue) + path segments of the next (closest_queue) in one persistent launch
+__global__ void __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace_mixed(DevScene sc, PathState ps, const uint32_t* __restrict__ any_queue,
+                                                  const unsigned int* __restrict__ n_any_ptr, const uint32_t* __restrict__ closest_queue,
+                                                  const unsigned int* __restrict__ n_closest_ptr, Counters* ctr, unsigned int* work_head,
+                                                  unsigned int refill_min) {
+    trace_body<kTraceMixed, false>(sc, ps, any_queue, *n_any_ptr, closest_queue, *n_closest_ptr, nullptr, ctr, work_head, refill_min);
 }
 
 // render_pixel up to the camera ray (craytracer.rs:148-156) for every path of a pass.

@@ -99,7 +99,8 @@ typedef struct {
                                    pixels of other tiles are left 0 in out_rgb. (0,1) = whole film */
     uint32_t sample_begin, sample_end; /* render samples [begin,end); (0,0) = all. Always divides by num_samples */
     uint32_t out_is_device;     /* 0: out_rgb is host memory; 1: device memory on the ctx's GPU */
-    uint32_t count_traversal;   /* 1: also count BVH nodes / primitive tests (cray_stats) */
+    uint32_t count_traversal;   /* 1: also count BVH nodes / primitive tests (cray_stats) of EVERY query the reference
+                                   makes; 2: count only the queries actually traversed (zero-term shadow rays skipped) */
     uint64_t max_paths_in_flight; /* 0 = default */
 } cray_render_params;
 
@@ -117,6 +118,9 @@ typedef struct {
     double seconds;                         /* first launch -> film complete, host clock around a device sync */
     double trace_closest_ms, trace_any_ms, shade_ms, other_ms; /* HIP-event time per kernel family */
     uint32_t trace_closest_launches, trace_any_launches, shade_launches, pad_;
+    double trace_mixed_ms;                  /* launches that trace the shadow rays of bounce b together with the
+                                               path segments of bounce b+1 (not used with count_traversal) */
+    uint32_t trace_mixed_launches, pad2_;
 } cray_stats;
 
 /* test hook: batched Scene::intersect / Scene::intersects */

@@ -23,7 +23,7 @@ for name in which:
            'frame_s': round(st['seconds'], 4), 'mray_s': round(traced / st['seconds'] / 1e6, 1), 'paths': st['paths'],
            'closest_rays': st['closest_rays'], 'shadow_rays': st['shadow_rays'], 'shadow_skipped': st['shadow_skipped'],
            'nonfinite': st['nonfinite'], 'stack_overflow': st['stack_overflow'], 'mean': float(film.mean()),
-           'kernel_ms': {k: round(st[k], 1) for k in ('trace_closest_ms', 'trace_any_ms', 'shade_ms', 'other_ms')}}
+           'kernel_ms': {k: round(st[k], 1) for k in ('trace_closest_ms', 'trace_mixed_ms', 'trace_any_ms', 'shade_ms', 'other_ms')}}
     # sampled parity: first sample of the frame, whole image, against the oracle
     orc = ol.OracleScene(sc)
     g, gst = dev.render(seed=0, sample_range=(0, 1), count_traversal=True)

@@ -46,7 +46,7 @@ def main():
                     best = (dt, st)
             dt, st = best
             per_rank.append({'rank': rank, 'ms': round(dt * 1e3, 2), 'rays': st['closest_rays'] + st['shadow_rays'] - st['shadow_skipped'],
-                             'closest_ms': round(st['trace_closest_ms'], 2), 'any_ms': round(st['trace_any_ms'], 2),
+                             'closest_ms': round(st['trace_closest_ms'], 2), 'mixed_ms': round(st['trace_mixed_ms'], 2), 'any_ms': round(st['trace_any_ms'], 2),
                              'shade_ms': round(st['shade_ms'], 2), 'other_ms': round(st['other_ms'], 2)})
         worst = max(r['ms'] for r in per_rank)
         if base is None:

@@ -36,8 +36,14 @@ if __name__ == '__main__':
         ws, wc = per_kernel(sys.argv[3], 'WRITE_SIZE')
         for k in ws:
             entry['kernels'].setdefault(k, {})['write_bytes_per_launch'] = ws[k] * 1024 / wc[k]
-    kc = entry['kernels'].get('k_trace<false, false>', {})
-    entry['trace_closest_bytes_per_launch'] = round(kc.get('fetch_bytes_per_launch', 0) + kc.get('write_bytes_per_launch', 0))
+    # the traversal family (k_trace<closest>, k_trace_mixed, k_trace<any>): HBM bytes per launch over all its launches
+    tot, launches = 0.0, 0
+    for k, v in entry['kernels'].items():
+        if k.startswith('k_trace'):
+            tot += (v.get('fetch_bytes_per_launch', 0) + v.get('write_bytes_per_launch', 0)) * v['launches']
+            launches += v['launches']
+    entry['trace_launches'] = launches
+    entry['trace_bytes_per_launch'] = round(tot / max(1, launches))
     data[workload] = entry
     json.dump(data, open(path, 'w'), indent=1)
     print(json.dumps(entry, indent=1))
