@@ -210,9 +210,6 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
             }
         } else if (active) {
             const uint32_t first = ref_leaf_first(cur), count = ref_leaf_count(cur);
-#ifdef CRAY_EXP_NO_LEAF
-            if (false)
-#endif
             for (uint32_t k = 0; k < count; k++) {
                 if (k > 0) {  // further primitives of the leaf (13 % of the leaves hold 2, none more than 4)
                     const double2* rec = reinterpret_cast<const double2*>(sc.slots + first + k);

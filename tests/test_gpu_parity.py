@@ -112,3 +112,27 @@ def test_small_path_pool_matches(setup):
     a, _ = dev.render(seed=2)
     b, _ = dev.render(seed=2, max_paths_in_flight=1000)
     assert np.array_equal(a, b)
+
+
+def test_fast_path_film_is_the_counting_path_film_and_the_oracle_film(setup):
+    """The timed configuration (zero-term shadow rays skipped, no light sampling for materials without a diffuse
+    lobe, shadow rays of bounce b traced together with the segments of bounce b+1) must produce the very film of
+    the instrumented configuration (every reference query traced, one launch per query kind) — and that film is
+    the oracle's, pixel for pixel."""
+    name, sc, host, dev, orc = setup
+    fast, fst = dev.render(seed=0)
+    slow, sst = dev.render(seed=0, count_traversal=True)
+    part, pst = dev.render(seed=0, count_traversal=2)
+    o, ost = orc.render(seed=0)
+    assert np.array_equal(fast, slow) and np.array_equal(fast, part)
+    assert np.array_equal(fast, o.astype(np.float32))
+    assert fst['trace_mixed_launches'] > 0 and sst['trace_mixed_launches'] == 0
+    # the reference's query counts are reported in every mode; skipped ones are a subset of the shadow rays
+    for st in (fst, sst, pst):
+        assert st['closest_rays'] == ost['closest_rays'] and st['shadow_rays'] == ost['shadow_rays']
+    assert sst['shadow_skipped'] == 0 and fst['shadow_skipped'] == pst['shadow_skipped'] <= fst['shadow_rays']
+    # count_traversal=2 counts only what the fast path traverses: same closest work, no more shadow work
+    assert pst['closest_nodes'] == sst['closest_nodes'] and pst['closest_prims'] == sst['closest_prims']
+    assert pst['shadow_nodes'] <= sst['shadow_nodes'] and pst['shadow_prims'] <= sst['shadow_prims']
+    if pst['shadow_skipped'] == 0:
+        assert pst['shadow_nodes'] == sst['shadow_nodes']
