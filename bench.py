@@ -34,6 +34,7 @@ WORKLOADS = {
     # name: (scene factory kwargs, description)
     'dragon': dict(width=1920, height=1080, spp=64, max_depth=8, nu=1200, nv=3000),
     'dragon_small': dict(width=480, height=270, spp=16, max_depth=8, nu=300, nv=750),
+    'dragon_4k': dict(width=3840, height=2160, spp=1024, max_depth=8, nu=1200, nv=3000),  # configs[4], meant for 8 GPUs
 }
 
 

@@ -19,6 +19,7 @@ def main():
     ap.add_argument('--workload', default='dragon')
     ap.add_argument('--worlds', default='1,2,4,8')
     ap.add_argument('--reps', type=int, default=2)
+    ap.add_argument('--ranks', default='', help='comma list: time only these ranks of each world')
     args = ap.parse_args()
     import torch
     import bench
@@ -30,11 +31,12 @@ def main():
     ctx = backend.Context(0, stream=torch.cuda.current_stream().cuda_stream)
     dev = ctx.upload(host)
     film = torch.zeros((H, W, 3), dtype=torch.float32, device='cuda')
-    dev.render(seed=0, out_device_ptr=film.data_ptr())
+    w0 = int(args.worlds.split(',')[0])
+    dev.render(seed=0, rank=0, world_size=w0, out_device_ptr=film.data_ptr(), sample_range=(0, min(8, wl['spp'])))  # warm-up
     base = None
     for world in [int(w) for w in args.worlds.split(',')]:
         per_rank = []
-        for rank in range(world):
+        for rank in ([int(r) for r in args.ranks.split(',')] if args.ranks else range(world)):
             best = None
             for _ in range(args.reps):
                 torch.cuda.synchronize()
@@ -51,7 +53,7 @@ def main():
         worst = max(r['ms'] for r in per_rank)
         if base is None:
             base = worst
-        print(json.dumps({'world': world, 'slowest_rank_ms': worst, 'mean_rank_ms': round(sum(r['ms'] for r in per_rank) / world, 2),
+        print(json.dumps({'world': world, 'slowest_rank_ms': worst, 'mean_rank_ms': round(sum(r['ms'] for r in per_rank) / len(per_rank), 2),
                           'speedup_vs_1': round(base / worst, 2), 'ranks': per_rank}), flush=True)
 
 
