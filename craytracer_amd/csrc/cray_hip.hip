@@ -581,10 +581,10 @@ extern "C" int cray_render(cray_ctx* c, cray_scene* s, const cray_render_params*
     if (staging) (void)hipFree(staging);
     if (err != hipSuccess) { set_last_error("render failed: %s", hipGetErrorString(err)); return CRAY_ERR_HIP; }
 
+    Counters h;
+    HIP_TRY(hipMemcpy(&h, c->counters, sizeof(h), hipMemcpyDeviceToHost));
     if (stats) {
         memset(stats, 0, sizeof(*stats));
-        Counters h;
-        HIP_TRY(hipMemcpy(&h, c->counters, sizeof(h), hipMemcpyDeviceToHost));
         fill_stats(h, stats);
         stats->paths = need;
         stats->seconds = std::chrono::duration<double>(t1 - t0).count();
@@ -595,6 +595,10 @@ extern "C" int cray_render(cray_ctx* c, cray_scene* s, const cray_render_params*
         stats->shade_ms = ms[FAM_SHADE]; stats->other_ms = ms[FAM_OTHER];
         stats->trace_closest_launches = launches[FAM_CLOSEST]; stats->trace_any_launches = launches[FAM_ANY];
         stats->shade_launches = launches[FAM_SHADE];
+    }
+    if (h.stack_overflow) {  // a ray needed more than kStackDepth pending nodes: its result is not the reference's
+        set_last_error("BVH deeper than the %d-entry traversal stack: %llu wave(s) overflowed; the film is not valid", kStackDepth, h.stack_overflow);
+        return CRAY_ERR_UNSUPPORTED;
     }
     return CRAY_OK;
 }

@@ -136,3 +136,20 @@ def test_fast_path_film_is_the_counting_path_film_and_the_oracle_film(setup):
     assert pst['shadow_nodes'] <= sst['shadow_nodes'] and pst['shadow_prims'] <= sst['shadow_prims']
     if pst['shadow_skipped'] == 0:
         assert pst['shadow_nodes'] == sst['shadow_nodes']
+
+
+def test_bvh_deeper_than_the_traversal_stack_fails_loudly():
+    """220 nested triangles at x = 4^i (each large enough to fill the camera's cone) make the reference's SAH tree
+    a 120-level chain; a camera ray keeps one far child pending per level, more than the 96-entry traversal stack holds.  The render must refuse, not return a
+    film that silently differs from the reference's."""
+    from craytracer_amd import scene as S
+    tris = np.array([[(x, -x - 1, -x - 1), (x, 3 * x + 3, -x - 1), (x, -x - 1, 3 * x + 3)] for x in (4.0 ** i for i in range(220))], dtype=float)
+    white = S.Material.new_matte(S.Color(1, 1, 1), 0.0)
+    cam = S.Camera.perspective(S.Film(8, 8), (-5, 0.2, 0.2), (1, 0.2, 0.2), (0, 1, 0), 20)
+    sc = S.Scene(2, 1, cam, [S.Light.Point((0, 5, 0), S.Color.WHITE)], [S.Mesh(S.triangles_flat(tris), material=white)])
+    ctx = backend.Context(0)
+    dev = ctx.upload(backend.HostScene(sc))
+    with pytest.raises(backend.CrayError, match='traversal stack'):
+        dev.render(seed=0)
+    dev.close()
+    ctx.close()
