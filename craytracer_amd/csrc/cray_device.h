@@ -121,6 +121,11 @@ struct Counters {
     unsigned int n_active[2], n_shadow, trace_head;
     unsigned int n_class[kShadeClasses];
     unsigned long long diag[16];  // k_trace lane-occupancy diagnostics (CRAY_TRACE_DIAG builds only)
+    // Third level of the traversal stack (LDS -> scratch -> here): entries kStackDepth.. of every lane, in global
+    // memory as [entry][global thread].  Allocated by the runtime only after a frame overflowed the first two levels.
+    uint32_t* deep_ref;
+    double* deep_key;
+    unsigned int deep_depth, deep_pad;
 };
 
 }  // namespace cray

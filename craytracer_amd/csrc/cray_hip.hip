@@ -62,6 +62,11 @@ struct cray_ctx {
     uint32_t* shadow_queue = nullptr;
     uint32_t* class_queues = nullptr;  // kShadeClasses x capacity (material sort)
     int sort_shade = 0;
+    // third stack level (Counters::deep_*), allocated after a frame overflowed LDS + scratch
+    uint32_t* deep_ref = nullptr;
+    double* deep_key = nullptr;
+    unsigned int deep_depth = 0;
+    size_t deep_threads = 0;
     int mix_trace = 1;  // shadow rays of bounce b and segments of bounce b+1 in one launch (CRAY_MIX_TRACE=0 disables)
     Counters* counters = nullptr;
     uint32_t* pix_list = nullptr;
@@ -123,6 +128,31 @@ int ensure_state(cray_ctx* c, size_t capacity) {
     if ((r = alloc(capacity * 4, (void**)&c->shadow_queue))) return r;
     if (c->sort_shade && (r = alloc(capacity * 4 * kShadeClasses, (void**)&c->class_queues))) return r;
     c->capacity = capacity;
+    return CRAY_OK;
+}
+
+// zero the device counters, keeping the description of the third stack level
+int reset_counters(cray_ctx* c) {
+    HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(Counters), c->stream));
+    if (c->deep_depth) {
+        struct { uint32_t* r; double* k; unsigned int d, pad; } v{c->deep_ref, c->deep_key, c->deep_depth, 0u};
+        static_assert(sizeof(v) == sizeof(Counters) - offsetof(Counters, deep_ref), "deep_* are the tail of Counters");
+        HIP_TRY(hipMemcpyAsync(&c->counters->deep_ref, &v, sizeof(v), hipMemcpyHostToDevice, c->stream));
+    }
+    return CRAY_OK;
+}
+
+// The reference's traversal has no depth limit (recursion / Vec); here a ray may keep kStackDepth nodes pending in
+// LDS + scratch.  When a frame reports an overflow the runtime adds this third level in HBM and renders again.
+constexpr unsigned int kDeepDepth = 2000;
+int ensure_deep(cray_ctx* c) {
+    if (c->deep_depth) return CRAY_OK;
+    const size_t threads = (size_t)c->n_cu * (size_t)(c->trace_blocks_per_cu > 8 ? c->trace_blocks_per_cu : 8) * kBlock;
+    HIP_TRY(hipMalloc((void**)&c->deep_ref, threads * kDeepDepth * sizeof(uint32_t)));
+    hipError_t e = hipMalloc((void**)&c->deep_key, threads * kDeepDepth * sizeof(double));
+    if (e != hipSuccess) { (void)hipFree(c->deep_ref); c->deep_ref = nullptr; set_last_error("hipMalloc of the deep traversal stack failed: %s", hipGetErrorString(e)); return CRAY_ERR_HIP; }
+    c->deep_threads = threads;
+    c->deep_depth = kDeepDepth;
     return CRAY_OK;
 }
 
@@ -220,6 +250,8 @@ extern "C" void cray_ctx_destroy(cray_ctx* c) {
     (void)hipSetDevice(c->device);
     for (void* p : c->state_allocs) (void)hipFree(p);
     if (c->counters) (void)hipFree(c->counters);
+    if (c->deep_ref) (void)hipFree(c->deep_ref);
+    if (c->deep_key) (void)hipFree(c->deep_key);
     if (c->pix_list) (void)hipFree(c->pix_list);
     if (c->film) (void)hipFree(c->film);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
@@ -559,7 +591,7 @@ extern "C" int cray_render(cray_ctx* c, cray_scene* s, const cray_render_params*
 
     if (!pix.empty()) HIP_TRY(hipMemcpyAsync(c->pix_list, pix.data(), pix.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->film, 0, film_floats * sizeof(float), c->stream));
-    HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(Counters), c->stream));
+    if ((e = reset_counters(c))) return e;
     HIP_TRY(hipStreamSynchronize(c->stream));
 
     EventTimer timer(c);
@@ -596,8 +628,14 @@ extern "C" int cray_render(cray_ctx* c, cray_scene* s, const cray_render_params*
         stats->trace_closest_launches = launches[FAM_CLOSEST]; stats->trace_any_launches = launches[FAM_ANY];
         stats->shade_launches = launches[FAM_SHADE];
     }
-    if (h.stack_overflow) {  // a ray needed more than kStackDepth pending nodes: its result is not the reference's
-        set_last_error("BVH deeper than the %d-entry traversal stack: %llu wave(s) overflowed; the film is not valid", kStackDepth, h.stack_overflow);
+    if (h.stack_overflow) {  // a ray needed more pending nodes than the traversal stack holds: its result is not the reference's
+        if (c->deep_depth == 0) {
+            // first time on this context: add the third stack level (HBM) and render the frame again
+            if ((e = ensure_deep(c))) return e;
+            return cray_render(c, s, prm, out_rgb, stats);
+        }
+        set_last_error("BVH deeper than the %u-entry traversal stack: %llu lane(s) overflowed; the film is not valid",
+                       (unsigned)kStackDepth + c->deep_depth, h.stack_overflow);
         return CRAY_ERR_UNSUPPORTED;
     }
     return CRAY_OK;
@@ -634,7 +672,7 @@ extern "C" int cray_render_samples(cray_ctx* c, cray_scene* s, const cray_render
     if ((e = ensure_state(c, n_pix * n))) return e;
     HIP_TRY(hipMemcpyAsync(c->pix_list, pix.data(), pix.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->film, 0, film_floats * sizeof(float), c->stream));
-    HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(Counters), c->stream));
+    if ((e = reset_counters(c))) return e;
     HIP_TRY(hipStreamSynchronize(c->stream));
     cray_render_params p2 = *prm;
     p2.sample_batch = n > p2.sample_batch ? n : p2.sample_batch;
@@ -669,7 +707,7 @@ extern "C" int cray_trace(cray_ctx* c, cray_scene* s, const cray_ray* rays, size
     }
     for (size_t i = 0; i < n; i++) col[i] = rays[i].tmax;
     HIP_TRY(hipMemcpy(ps.stmax, col.data(), n * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(Counters), c->stream));
+    if ((e = reset_counters(c))) return e;
     // any-hit resolution adds `contribution` to L: use L as the "unoccluded" flag (0 + 1)
     if (any_hit) {
         for (size_t i = 0; i < n; i++) col[i] = 0.0;
@@ -702,10 +740,18 @@ extern "C" int cray_trace(cray_ctx* c, cray_scene* s, const cray_ray* rays, size
         (void)hipFree(d_hits);
         if (err != hipSuccess) { set_last_error("cray_trace failed: %s", hipGetErrorString(err)); return CRAY_ERR_HIP; }
     }
+    Counters h;
+    HIP_TRY(hipMemcpy(&h, c->counters, sizeof(h), hipMemcpyDeviceToHost));
+    if (h.stack_overflow) {
+        if (c->deep_depth == 0) {
+            if ((e = ensure_deep(c))) return e;
+            return cray_trace(c, s, rays, n, hits, any_hit, stats);
+        }
+        set_last_error("BVH deeper than the %u-entry traversal stack", (unsigned)kStackDepth + c->deep_depth);
+        return CRAY_ERR_UNSUPPORTED;
+    }
     if (stats) {
         memset(stats, 0, sizeof(*stats));
-        Counters h;
-        HIP_TRY(hipMemcpy(&h, c->counters, sizeof(h), hipMemcpyDeviceToHost));
         fill_stats(h, stats);
     }
     return CRAY_OK;

@@ -72,7 +72,10 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
     do {                                                                                   \
         if (sp < kLdsStack) { lds_ref[sp * kBlock + tid] = (r_); lds_key[sp * kBlock + tid] = (k_); sp++; } \
         else if (sp < kStackDepth) { sref[sp - kLdsStack] = (r_); skey[sp - kLdsStack] = (k_); sp++; }      \
-        else overflow = 1;                                                                 \
+        else if (sp < kStackDepth + (int)ctr->deep_depth) {                                \
+            const size_t at_ = (size_t)(sp - kStackDepth) * ((size_t)gridDim.x * kBlock) + (size_t)blockIdx.x * kBlock + tid; \
+            ctr->deep_ref[at_] = (r_); ctr->deep_key[at_] = (k_); sp++;                    \
+        } else overflow = 1;                                                               \
     } while (0)
     int sp = 0;
     bool active = false, exhausted = false;
@@ -244,8 +247,15 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
                 if (sp == 0) { finished = true; break; }
                 --sp;
                 if (COUNT && ANY) n_nodes += 1;
-                const double key = sp < kLdsStack ? lds_key[sp * kBlock + tid] : skey[sp - kLdsStack];
-                if (key < ray.tmax) { cur = sp < kLdsStack ? lds_ref[sp * kBlock + tid] : sref[sp - kLdsStack]; break; }
+                double key;
+                uint32_t ref;
+                if (sp < kLdsStack) { key = lds_key[sp * kBlock + tid]; ref = lds_ref[sp * kBlock + tid]; }
+                else if (sp < kStackDepth) { key = skey[sp - kLdsStack]; ref = sref[sp - kLdsStack]; }
+                else {
+                    const size_t at = (size_t)(sp - kStackDepth) * ((size_t)gridDim.x * kBlock) + (size_t)blockIdx.x * kBlock + tid;
+                    key = ctr->deep_key[at]; ref = ctr->deep_ref[at];
+                }
+                if (key < ray.tmax) { cur = ref; break; }
             }
         }
         if (active && finished) {

@@ -114,7 +114,9 @@ typedef struct {
     uint64_t shadow_nodes, shadow_prims;
     uint64_t closest_tri_tests, shadow_tri_tests;
     uint64_t nonfinite;                     /* paths where the reference's assert!(is_finite) would fire */
-    uint64_t stack_overflow;                /* traversal stack overflows (must be 0) */
+    uint64_t stack_overflow;                /* lanes whose traversal stack overflowed: 0 in every successful call (the runtime
+                                               adds a deeper stack level and repeats the work; beyond ~2100 pending nodes per
+                                               ray the call fails with CRAY_ERR_UNSUPPORTED) */
     double seconds;                         /* first launch -> film complete, host clock around a device sync */
     double trace_closest_ms, trace_any_ms, shade_ms, other_ms; /* HIP-event time per kernel family */
     uint32_t trace_closest_launches, trace_any_launches, shade_launches, pad_;
