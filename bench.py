@@ -63,10 +63,18 @@ def main():
     if world != args.gpus:
         log('warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE' % (world, args.gpus))
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the backend has no CPU fallback)'
+    # One process per GPU over RCCL.  CRAY_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than
+    # ranks (ranks then share GPUs and the tile gather is staged through the host); never used for reported numbers.
+    dist_backend = os.environ.get('CRAY_BENCH_BACKEND', 'nccl')
+    if dist_backend != 'nccl':
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        if dist_backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(dist_backend, rank=rank, world_size=world)
 
     from craytracer_amd import backend, scenes
     from craytracer_amd import dist as cdist
@@ -185,7 +193,7 @@ def main():
             'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'configs[2]: dragon.cry camera/materials/lights, procedural %d-triangle mesh, %dx%d, %d spp, depth %d'
                                    % (len(scene.triangles), W, H, wl['spp'], wl['max_depth']),
-                       'parallelism': 'tile-shard x%d + RCCL gather of Film tiles' % world if world > 1 else 'single GPU',
+                       'parallelism': ('tile-shard x%d + RCCL gather of Film tiles' % world if dist_backend == 'nccl' else 'REHEARSAL: %d ranks sharing GPUs, gloo' % world) if world > 1 else 'single GPU',
                        'seconds_per_frame': round(elapsed / args.steps, 4),
                        'mpaths_per_s': round(W * H * wl['spp'] * args.steps / elapsed / 1e6, 2),
                        'rays_per_frame': int(total_rays / args.steps),

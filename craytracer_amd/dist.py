@@ -61,11 +61,17 @@ class FilmGather:
         if self.world == 1:
             return local_film
         torch.index_select(local_film.reshape(-1, 3), 0, self.mine, out=self.packed)
+        staged = self.packed.is_cuda and dist.get_backend(self.group) == 'gloo'  # gloo gathers host tensors only
         if self.rank == 0:
-            dist.gather(self.packed, gather_list=list(self.parts.unbind(0)), dst=0, group=self.group)
+            if staged:
+                parts = [torch.empty(self.packed.shape, dtype=torch.float32) for _ in range(self.world)]
+                dist.gather(self.packed.cpu(), gather_list=parts, dst=0, group=self.group)
+                self.parts.copy_(torch.stack(parts))
+            else:
+                dist.gather(self.packed, gather_list=list(self.parts.unbind(0)), dst=0, group=self.group)
             torch.index_select(self.parts.reshape(-1, 3), 0, self.where, out=self.out)
             return self.out.reshape(self.height, self.width, 3)
-        dist.gather(self.packed, gather_list=None, dst=0, group=self.group)
+        dist.gather(self.packed.cpu() if staged else self.packed, gather_list=None, dst=0, group=self.group)
         return None
 
 
