@@ -1639,6 +1639,37 @@ void orc_color_from_rgb(uint8_t r, uint8_t g, uint8_t b, double* out) {
     Col c = from_rgb(r, g, b); out[0] = c.r; out[1] = c.g; out[2] = c.b;
 }
 void orc_color_to_rgb(const double* c, uint8_t* out) { to_rgb(col(c[0], c[1], c[2]), out); }
+/* probes of the arithmetic types the path is built from (geometry/vector.rs, point.rs, color.rs, bounds.rs) */
+void orc_vec_op(int op, const double* a, const double* b, double s, double* out) {
+    V3 x = v3(a[0], a[1], a[2]), y = b ? v3(b[0], b[1], b[2]) : v3(0, 0, 0), r = v3(0, 0, 0);
+    switch (op) {
+        case 0: r = normalized(x); break;
+        case 1: out[0] = magnitude(x); return;
+        case 2: out[0] = dot(x, y); return;
+        case 3: r = cross(x, y); break;
+        case 4: r = x + y; break;
+        case 5: r = x - y; break;
+        case 6: r = x * s; break;
+        case 7: r = x / s; break;
+        default: break;
+    }
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+void orc_col_op(int op, const double* a, const double* b, double s, double* out) {
+    Col x = col(a[0], a[1], a[2]), y = b ? col(b[0], b[1], b[2]) : col(0, 0, 0), r = x;
+    switch (op) {
+        case 0: r = x + y; break;
+        case 1: r = x * s; break;
+        case 2: r = x / s; break;
+        case 3: r = x * y; break;
+        default: break;
+    }
+    out[0] = r.r; out[1] = r.g; out[2] = r.b;
+}
+void orc_bounds_sum(const double* a6, const double* b6, double* out6) {
+    Bounds r = bounds_union(bounds_new(v3(a6[0], a6[1], a6[2]), v3(a6[3], a6[4], a6[5])), bounds_new(v3(b6[0], b6[1], b6[2]), v3(b6[3], b6[4], b6[5])));
+    out6[0] = r.mn.x; out6[1] = r.mn.y; out6[2] = r.mn.z; out6[3] = r.mx.x; out6[4] = r.mx.y; out6[5] = r.mx.z;
+}
 /* partition_by over i64 with predicate (x % mod == rem) or (x > thr) */
 uint64_t orc_partition_by(int64_t* data, uint64_t n, int mode, int64_t a, int64_t b) {
     return partition_by(data, (size_t)n, [&](const int64_t& x) { return mode == 0 ? (x > a) : (((x % a) + a) % a == b); });

@@ -295,3 +295,58 @@ def test_pixel_hash_is_siphash13_of_three_le_words():
                             dtype=np.uint8).copy()
         full = L.orc_siphash(msg.ctypes.data, 24, 0, 0, 1, 3)
         assert L.orc_pixel_hash(seed, x, y) == (full & 0xffffffff)
+
+
+# --- tests/test_geometry.rs:9-105 (vector), :108-152 (point: the same component arithmetic) ---------------
+def vec_op(op, a, b=None, s=0.0, n=3):
+    out = np.zeros(3)
+    aa, bb = f64(*a), (f64(*b) if b is not None else None)   # keep the arrays alive across the call
+    L.orc_vec_op(op, aa.ctypes.data, bb.ctypes.data if bb is not None else None, float(s), out.ctypes.data)
+    return tuple(out[:n])
+
+
+def test_vector_and_point_arithmetic():
+    X, Y, Z = (1, 0, 0), (0, 1, 0), (0, 0, 1)
+    assert vec_op(0, (1, 2, 2)) == (1.0 / 3.0, 2.0 / 3.0, 2.0 / 3.0)          # normalized, exact equality in the reference
+    assert vec_op(1, (1, 2, 2), n=1) == (3.0,)                                   # magnitude
+    assert vec_op(2, (1, 2, 3), (-2, 2, 0.5), n=1) == (3.5,)                     # dot
+    assert vec_op(3, X, Y) == Z and vec_op(3, Y, Z) == X and vec_op(3, Z, X) == Y
+    a = (1, 1, 0)
+    assert vec_op(3, a, a) == (0, 0, 0)
+    assert vec_op(3, a, X) == (0, 0, -1) and vec_op(3, a, Y) == (0, 0, 1) and vec_op(3, a, Z) == (1, -1, 0)
+    assert vec_op(4, (1, 2, 3), (1, 1, 1)) == (2, 3, 4)                          # add / add_assign / point + vector
+    assert vec_op(5, (1, 2, 3), (1, 1, 1)) == (0, 1, 2)                          # sub / sub_assign / point - point / point - vector
+    assert vec_op(6, (1, 2, 3), s=2.0) == (2, 4, 6)                              # mul / mul_assign
+    assert vec_op(7, (1, 2, 3), s=2.0) == (0.5, 1.0, 1.5)                        # div
+    assert vec_op(6, (1, 2, 3), s=0.5) == (0.5, 1.0, 1.5)                        # "div_assign" in the reference is `*= 0.5`
+    assert vec_op(4, (1, 2, 3), (1, 1, 1)) != (1, 2, 3)                          # equal / not equal
+
+
+# --- tests/test_color.rs:18-135 -------------------------------------------------------------------------------
+def test_color_arithmetic_and_to_rgb():
+    def col_op(op, a, b=None, s=0.0):
+        out = np.zeros(3)
+        aa, bb = f64(*a), (f64(*b) if b is not None else None)
+        L.orc_col_op(op, aa.ctypes.data, bb.ctypes.data if bb is not None else None, float(s), out.ctypes.data)
+        return tuple(out)
+    assert col_op(0, (1, 2, 3), (1, 1, 1)) == (2, 3, 4)      # add, add_assign
+    assert col_op(1, (1, 2, 3), s=2.0) == (2, 4, 6)           # mul, mul_assign
+    assert col_op(2, (1, 2, 3), s=2.0) == (0.5, 1.0, 1.5)     # div
+    assert col_op(1, (1, 2, 3), s=0.5) == (0.5, 1.0, 1.5)     # div_assign (`*= 0.5`)
+    c = np.zeros(3)
+    L.orc_color_from_rgb(255, 128, 0, c.ctypes.data)          # to_rgb(from_rgb(255, 128, 0)) == (255, 128, 0)
+    rgb = np.zeros(3, dtype=np.uint8)
+    L.orc_color_to_rgb(c.ctypes.data, rgb.ctypes.data)
+    assert tuple(int(v) for v in rgb) == (255, 128, 0)
+
+
+# --- tests/test_bounds.rs:66-108 -----------------------------------------------------------------------------
+def test_bounds_sum():
+    def bsum(a, b):
+        out = np.zeros(6)
+        aa, bb = f64(*a), f64(*b)
+        L.orc_bounds_sum(aa.ctypes.data, bb.ctypes.data, out.ctypes.data)
+        return tuple(out)
+    assert bsum((0, 0, 0, 1, 0, 0), (0, 0, 0, 1, 0, 0)) == (0, 0, 0, 1, 0, 0)
+    assert bsum((0, 0, 0, 1, 0, 0), (0, 0, 0, 0, 1, 0)) == (0, 0, 0, 1, 1, 0)
+    assert bsum((0, 0, 0, 1, 1, 1), (2, 2, 2, 3, 3, 3)) == (0, 0, 0, 3, 3, 3)
