@@ -398,7 +398,19 @@ extern "C" int cray_scene_upload(cray_ctx* c, const cray_flat_scene* f, cray_sce
     if (!e) e = upload(s, shade.data(), shade.size(), &d.tri_shade);
     if (!e) e = upload(s, f->spheres, (size_t)f->n_spheres, &d.spheres);
     if (!e) e = upload(s, f->disks, (size_t)f->n_disks, &d.disks);
-    if (!e) e = upload(s, f->materials, (size_t)f->n_materials, &d.materials);
+    // device copy of the materials with pad_ = "some lobe reads a non-constant texture": only then does k_shade
+    // need the (u, v) of a sphere / disk hit (atan2 + acos per hit otherwise computed for nothing)
+    std::vector<cray_material> mats(f->materials, f->materials + f->n_materials);
+    for (cray_material& m : mats) {
+        m.pad_ = 0;
+        const int nb = m.is_bsdf ? m.n_bxdfs : 1;
+        for (int i = 0; i < nb; i++) {
+            const cray_bxdf& bx = f->bxdfs[m.first_bxdf + i];
+            for (int32_t t : {bx.tex_a, bx.tex_b})
+                if (t >= 0 && f->textures[t].kind != CRAY_TEX_CONSTANT) m.pad_ = 1;
+        }
+    }
+    if (!e) e = upload(s, mats.data(), mats.size(), &d.materials);
     if (!e) e = upload(s, f->bxdfs, (size_t)f->n_bxdfs, &d.bxdfs);
     if (!e) e = upload(s, f->textures, (size_t)f->n_textures, &d.textures);
     if (!e) e = upload(s, f->images, (size_t)f->n_images, &d.images);

@@ -431,9 +431,9 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
                 ps.lr[p] = L.r; ps.lg[p] = L.g; ps.lb[p] = L.b;
             } else {
                 const cray_prim pr = sc.prims[hp];
-                const SurfPoint sp = surface_at(sc, pr, ray, ps.ht[p], ps.hu[p], ps.hv[p]);
-                const vec3 n_s = sp.normal, x = sp.location;
                 const int32_t mat = pr.light >= 0 ? -1 : pr.material;
+                const SurfPoint sp = surface_at(sc, pr, ray, ps.ht[p], ps.hu[p], ps.hv[p], mat >= 0 && sc.materials[mat].pad_ != 0);
+                const vec3 n_s = sp.normal, x = sp.location;
 
                 // PathSegmentSamples::from (path_integrator.rs:26-36): dims 4+8k .. 11+8k
                 const uint32_t sidx = s_lo + p % spp_pass;
@@ -655,7 +655,7 @@ __global__ void __launch_bounds__(kBlock) k_hit_records(DevScene sc, PathState p
         h.uv[0] = 0.0; h.uv[1] = 0.0;
         if (h.hit) {
             ray_t ray = mkray(mk(ps.ox[p], ps.oy[p], ps.oz[p]), mk(ps.dx[p], ps.dy[p], ps.dz[p]));
-            SurfPoint sp = surface_at(sc, sc.prims[h.prim], ray, ps.ht[p], ps.hu[p], ps.hv[p]);
+            SurfPoint sp = surface_at(sc, sc.prims[h.prim], ray, ps.ht[p], ps.hu[p], ps.hv[p], true);
             h.location[0] = sp.location.x; h.location[1] = sp.location.y; h.location[2] = sp.location.z;
             h.normal[0] = sp.normal.x; h.normal[1] = sp.normal.y; h.normal[2] = sp.normal.z;
             h.uv[0] = sp.u; h.uv[1] = sp.v;

@@ -203,8 +203,11 @@ __device__ inline bool disk_hit(const cray_xf_shape& s, ray_t& ray, bool any_onl
 // Location / normal / uv of a closest hit found by the traversal kernel.  For sphere and
 // disk the shape code is re-run on the recorded distance: same inputs, same operations,
 // hence the same bits the reference computed eagerly inside Shape::intersect.
-__device__ inline SurfPoint surface_at(const DevScene& sc, const cray_prim& pr, const ray_t& ray_in, double t, double bu, double bv) {
+// need_uv = false leaves (u, v) of a sphere / disk hit at 0: for materials whose textures are all constant the
+// reference computes them (atan2, acos) and never looks at them.
+__device__ inline SurfPoint surface_at(const DevScene& sc, const cray_prim& pr, const ray_t& ray_in, double t, double bu, double bv, bool need_uv) {
     SurfPoint sp;
+    sp.u = 0.0; sp.v = 0.0;
     if (pr.shape_kind == CRAY_SHAPE_TRIANGLE) {
         const TriShade& ts = sc.tri_shade[pr.shape];
         sp.location = at(ray_in, t);
@@ -217,19 +220,23 @@ __device__ inline SurfPoint surface_at(const DevScene& sc, const cray_prim& pr, 
     vec3 oo = xf_point(s.inv, ray_in.o), od = xf_vector(s.inv, ray_in.d);
     if (pr.shape_kind == CRAY_SHAPE_SPHERE) {
         vec3 loc = oo + od * t;
-        double phi = atan2(loc.y, loc.x);
-        if (phi < 0.0) phi += kPi * 2.0;
-        sp.u = phi / (kPi * 2.0);
-        sp.v = acos(loc.z / s.radius) * kInvPi;
+        if (need_uv) {
+            double phi = atan2(loc.y, loc.x);
+            if (phi < 0.0) phi += kPi * 2.0;
+            sp.u = phi / (kPi * 2.0);
+            sp.v = acos(loc.z / s.radius) * kInvPi;
+        }
         sp.location = xf_point(s.m, loc);
         sp.normal = xf_normal(s.inv, loc / s.radius);
     } else {
         vec3 loc = mk(oo.x + od.x * t, oo.y + od.y * t, 0.0);
-        double d2 = square(loc.x) + square(loc.y);
-        double theta = atan2(loc.y, loc.x);
-        if (theta < 0.0) theta += kPi * 2.0;
-        sp.u = theta / (kPi * 2.0);
-        sp.v = sqrt(d2) / s.radius;
+        if (need_uv) {
+            double d2 = square(loc.x) + square(loc.y);
+            double theta = atan2(loc.y, loc.x);
+            if (theta < 0.0) theta += kPi * 2.0;
+            sp.u = theta / (kPi * 2.0);
+            sp.v = sqrt(d2) / s.radius;
+        }
         sp.location = xf_point(s.m, loc);
         sp.normal = xf_normal(s.inv, mk(0.0, 0.0, 1.0));
     }
