@@ -531,7 +531,9 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
                 ls.w_i = reflect(w_o, n_s); ls.f = mkc(1, 1, 1); ls.pdf = 1.0; ls.delta = true; ls.specular = true;
                 bool go = true;
 #else
-                bool go = material_sample(sc, mat, sa[0], sa[1], sa[2], w_o, n_s, sp.u, sp.v, ls);
+                // an area light's own surface is a black Lambertian (primitive.rs:40-46): its sampled f is BLACK, the
+                // path ends (`if f.is_black() { break }`, path_integrator.rs:176-178) whatever direction was drawn
+                bool go = mat >= 0 && material_sample(sc, mat, sa[0], sa[1], sa[2], w_o, n_s, sp.u, sp.v, ls);
 #endif
                 if (go && black(ls.f)) go = false;
                 double bsdf_pdf = 0.0;

@@ -124,7 +124,12 @@ struct xform {
 CRAY_HD vec3 xf_point(const double* m /*16, row-major*/, vec3 p) {
     vec3 r = mk(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7],
                 m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]);
-    return r / (m[12] * p.x + m[13] * p.y + m[14] * p.z + m[15]);
+    // Transformable<Point> divides by w (transformation.rs:420-429).  Every transformation the path applies to a
+    // point is affine (translate / rotate compositions): w is exactly 1.0 and x / 1.0 == x bit for bit, so the three
+    // divisions are skipped then; anything else (NaN, a projective matrix) takes the division.
+    const double w = m[12] * p.x + m[13] * p.y + m[14] * p.z + m[15];
+    if (w == 1.0) return r;
+    return r / w;
 }
 CRAY_HD vec3 xf_vector(const double* m, vec3 v) {  // :431-440
     return mk(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z,
