@@ -169,6 +169,25 @@ def main():
                     'avg_launch_ms': round(avg_ms, 4), 'launches_per_step': launches_per_frame,
                     'bytes_per_ray': round(alg_bytes_frame / max(1, traced), 1)}
 
+    # --- what a plain streaming read reaches on this very GPU (SURVEY.md §8d asks for the roofline against the
+    # measured figure next to the 8 TB/s spec): torch.sum over 4 GiB of f32, HIP events on the current stream
+    if roofline is not None and rank == 0:
+        try:
+            big = torch.empty(1 << 30, dtype=torch.float32, device='cuda').fill_(1.0)
+            torch.sum(big)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            for _ in range(5):
+                torch.sum(big)
+            ev1.record()
+            torch.cuda.synchronize()
+            stream_gbs = 5 * big.numel() * 4 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+            del big
+            roofline['measured_stream_read_GBs'] = round(stream_gbs, 1)
+            roofline['frac_of_measured_stream'] = round(roofline['achieved'] / stream_gbs, 5)
+        except Exception as e:  # measurement aid only
+            log('stream-read measurement skipped: %s' % e)
+
     # --- CPU baseline: the oracle on a bounded sample of the same workload (rank 0, N=1 only)
     cpu = None
     if rank == 0 and world == 1 and args.cpu_baseline:

@@ -71,6 +71,9 @@ struct cray_ctx {
     Counters* counters = nullptr;
     uint32_t* pix_list = nullptr;
     size_t pix_capacity = 0;
+    uint64_t pix_key[6] = {0, 0, 0, 0, 0, 0};  // (W, H, tile w, tile h, rank, world) of the list in pix_list
+    size_t pix_count = 0;
+    bool pix_count_valid = false;
     float* film = nullptr;
     size_t film_floats = 0;
     // event pool for per-family kernel timing
@@ -579,13 +582,21 @@ extern "C" int cray_render(cray_ctx* c, cray_scene* s, const cray_render_params*
     if (s_begin == 0 && s_end == 0) s_end = d.num_samples;
     if (s_end > d.num_samples) s_end = d.num_samples;
 
-    std::vector<uint32_t> pix = rank_pixels(W, H, *prm);
-    if (pix.size() > c->pix_capacity) {
-        if (c->pix_list) (void)hipFree(c->pix_list);
-        c->pix_list = nullptr; c->pix_capacity = 0;
-        HIP_TRY(hipMalloc((void**)&c->pix_list, pix.size() * 4));
-        c->pix_capacity = pix.size();
+    // the pixel list of (film, tiles, rank, world) stays on the device between frames
+    const uint64_t pix_key[6] = {W, H, prm->tile_width, prm->tile_height, prm->rank, prm->world_size};
+    const bool pix_cached = c->pix_count_valid && memcmp(pix_key, c->pix_key, sizeof(pix_key)) == 0;
+    std::vector<uint32_t> pix;
+    if (!pix_cached) {
+        pix = rank_pixels(W, H, *prm);
+        c->pix_count_valid = false;
+        if (pix.size() > c->pix_capacity) {
+            if (c->pix_list) (void)hipFree(c->pix_list);
+            c->pix_list = nullptr; c->pix_capacity = 0;
+            HIP_TRY(hipMalloc((void**)&c->pix_list, pix.size() * 4));
+            c->pix_capacity = pix.size();
+        }
     }
+    const size_t n_pix_rank = pix_cached ? c->pix_count : pix.size();
     const size_t film_floats = (size_t)W * H * 3;
     if (film_floats > c->film_floats) {
         if (c->film) (void)hipFree(c->film);
@@ -594,14 +605,20 @@ extern "C" int cray_render(cray_ctx* c, cray_scene* s, const cray_render_params*
         c->film_floats = film_floats;
     }
     size_t capacity = prm->max_paths_in_flight ? (size_t)prm->max_paths_in_flight : ((size_t)32 << 20);
-    size_t need = (size_t)pix.size() * (s_end > s_begin ? s_end - s_begin : 0);
+    size_t need = n_pix_rank * (s_end > s_begin ? s_end - s_begin : 0);
     if (need < capacity) capacity = need;
     if (capacity < prm->sample_batch) capacity = prm->sample_batch;
     if (capacity >= ((size_t)1 << 32)) capacity = ((size_t)1 << 32) - 1;
     if ((e = ensure_state(c, capacity))) return e;
-    std::vector<PassPlan> passes = plan(c->capacity, (uint32_t)pix.size(), s_begin, s_end, prm->sample_batch);
+    std::vector<PassPlan> passes = plan(c->capacity, (uint32_t)n_pix_rank, s_begin, s_end, prm->sample_batch);
 
-    if (!pix.empty()) HIP_TRY(hipMemcpyAsync(c->pix_list, pix.data(), pix.size() * 4, hipMemcpyHostToDevice, c->stream));
+    if (!pix_cached) {
+        if (!pix.empty()) HIP_TRY(hipMemcpyAsync(c->pix_list, pix.data(), pix.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));  // pix is a local vector
+        memcpy(c->pix_key, pix_key, sizeof(pix_key));
+        c->pix_count = pix.size();
+        c->pix_count_valid = true;
+    }
     HIP_TRY(hipMemsetAsync(c->film, 0, film_floats * sizeof(float), c->stream));
     if ((e = reset_counters(c))) return e;
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -668,6 +685,7 @@ extern "C" int cray_render_samples(cray_ctx* c, cray_scene* s, const cray_render
     if (n_pix * n >= ((size_t)1 << 32)) { set_last_error("cray_render_samples: too many paths"); return CRAY_ERR_UNSUPPORTED; }
     std::vector<uint32_t> pix(n_pix);
     for (size_t i = 0; i < n_pix; i++) pix[i] = (uint32_t)i;
+    c->pix_count_valid = false;  // this call overwrites the cached per-rank pixel list
     if (pix.size() > c->pix_capacity) {
         if (c->pix_list) (void)hipFree(c->pix_list);
         c->pix_list = nullptr; c->pix_capacity = 0;
