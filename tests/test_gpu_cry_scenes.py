@@ -30,3 +30,28 @@ def test_parsed_scene_renders_pixel_exact(name, w, h, spp):
     assert gst['nonfinite'] == 0
     dev.close()
     ctx.close()
+
+
+def test_command_line_writes_the_same_film_as_exr(tmp_path):
+    """`python -m craytracer_amd --scene .. --output out.exr` (the reference's CLI, craytracer.rs:321-370): the EXR
+    on disk holds exactly the film the library returns, which is the oracle's."""
+    from craytracer_amd.__main__ import main
+    path = os.path.join(GOLDEN, 'test.cry')
+    out = str(tmp_path / 'out.exr')
+    assert main(['--scene', path, '--output', out, '--seed', '5', '--width', '40', '--height', '30', '--spp', '4', '--max-depth', '5']) == 0
+    film = backend.read_exr(out)
+    sc = cry.load_scene_file(path, width=40, height=30, num_samples=4, max_depth=5)
+    o, _ = ol.OracleScene(sc).render(seed=5)
+    assert film.shape == (30, 40, 3)
+    assert np.array_equal(film, o.astype(np.float32))
+
+
+def test_command_line_reports_parse_errors_like_the_reference(tmp_path, capsys):
+    """craytracer.rs:348-354: the error is printed as `<message> at <file>:<line>:<col>` and the process ends normally."""
+    from craytracer_amd.__main__ import main
+    bad = tmp_path / 'bad.cry'
+    bad.write_text('{ max_depth: 3,\n  num_samples: }')
+    assert main(['--scene', str(bad), '--output', str(tmp_path / 'x.exr')]) == 0
+    err = capsys.readouterr().err
+    assert ' at ' in err and 'bad.cry:2:' in err
+    assert not (tmp_path / 'x.exr').exists()
