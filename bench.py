@@ -31,11 +31,25 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 B_NODE, B_TRI, B_OTHER, B_RAY = 64, 72, 48, 88
 
 WORKLOADS = {
-    # name: (scene factory kwargs, description)
-    'dragon': dict(width=1920, height=1080, spp=64, max_depth=8, nu=1200, nv=3000),
-    'dragon_small': dict(width=480, height=270, spp=16, max_depth=8, nu=300, nv=750),
-    'dragon_4k': dict(width=3840, height=2160, spp=1024, max_depth=8, nu=1200, nv=3000),  # configs[4], meant for 8 GPUs
+    # name: scene factory kwargs + 'scene' (factory in craytracer_amd.scenes) + 'label' (which BASELINE.json config it is)
+    'dragon': dict(scene='dragon', label='configs[2]: dragon.cry camera/materials/lights, procedural mesh',
+                   width=1920, height=1080, spp=64, max_depth=8, nu=1200, nv=3000),
+    'dragon_small': dict(scene='dragon', label='reduced configs[2] (smoke / rehearsal size)',
+                         width=480, height=270, spp=16, max_depth=8, nu=300, nv=750),
+    'dragon_4k': dict(scene='dragon', label='configs[4]: meant for 8 GPUs',
+                      width=3840, height=2160, spp=1024, max_depth=8, nu=1200, nv=3000),
+    # the other BASELINE.json configs are parity-test cases; they can be timed too, but are not the headline
+    'cornell': dict(scene='cornell', label='configs[1]: cornell.cry camera, procedural Cornell box', width=512, height=512, spp=64, max_depth=8),
+    'staircase': dict(scene='staircase', label='configs[3]: staircase.cry camera/lights, procedural interior',
+                      width=1920, height=1080, spp=256, max_depth=12),
 }
+
+
+def make_scene(scenes, name):
+    wl = dict(WORKLOADS[name])
+    factory = getattr(scenes, wl.pop('scene'))
+    wl.pop('label')
+    return factory(**wl)
 
 
 def log(*a):
@@ -81,7 +95,7 @@ def main():
 
     wl = WORKLOADS[args.workload]
     t0 = time.time()
-    scene = scenes.dragon(**wl)
+    scene = make_scene(scenes, args.workload)
     W, H = scene.film_bounds()
     t1 = time.time()
     stream = torch.cuda.current_stream()
@@ -206,12 +220,12 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = total_rays / elapsed / 1e6
         line = {
-            'metric': 'Mray/s (BVH queries actually traversed: Scene::intersect + Scene::intersects) on the 1920x1080x64spp dragon-class frame',
+            'metric': 'Mray/s (BVH queries actually traversed: Scene::intersect + Scene::intersects) on the %dx%dx%dspp %s frame' % (W, H, wl['spp'], 'dragon-class' if wl['scene'] == 'dragon' else wl['scene']),
             'value': round(value, 2), 'unit': 'Mray/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 2), 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'configs[2]: dragon.cry camera/materials/lights, procedural %d-triangle mesh, %dx%d, %d spp, depth %d'
-                                   % (len(scene.triangles), W, H, wl['spp'], wl['max_depth']),
+            'config': {'workload': '%s, %d triangles, %dx%d, %d spp, depth %d'
+                                   % (wl['label'], len(scene.triangles), W, H, wl['spp'], wl['max_depth']),
                        'parallelism': ('tile-shard x%d + RCCL gather of Film tiles' % world if dist_backend == 'nccl' else 'REHEARSAL: %d ranks sharing GPUs, gloo' % world) if world > 1 else 'single GPU',
                        'seconds_per_frame': round(elapsed / args.steps, 4),
                        'mpaths_per_s': round(W * H * wl['spp'] * args.steps / elapsed / 1e6, 2),

@@ -25,7 +25,7 @@ def main():
     import bench
     from craytracer_amd import backend, scenes
     wl = bench.WORKLOADS[args.workload]
-    scene = scenes.dragon(**wl)
+    scene = bench.make_scene(scenes, args.workload)
     W, H = scene.film_bounds()
     host = backend.HostScene(scene)
     ctx = backend.Context(0, stream=torch.cuda.current_stream().cuda_stream)
