@@ -162,3 +162,28 @@ def test_bvh_deeper_than_the_fast_traversal_stack_still_matches_the_oracle():
     assert np.array_equal(gh['hit'], oh['hit']) and np.array_equal(gh['t'], oh['t'])
     dev.close()
     ctx.close()
+
+
+@pytest.mark.parametrize('n_prims', [1, 2])
+def test_tiny_scenes_with_a_leaf_root_or_one_split(n_prims):
+    """A BVH that is a single leaf (one primitive) or one interior node over two leaves: the degenerate ends of
+    the traversal (root reference is a leaf; empty stack after the first step)."""
+    from craytracer_amd import scene as S
+    s_light = S.Shape.new_disk((0, 3, 0), 90, 0, 1.5, 0)
+    prims = [S.Primitive.new_area_light(s_light, S.Light.Area(s_light, S.Color(4, 4, 4)))]
+    if n_prims == 2:
+        prims.append(S.Primitive.new(S.Shape.new_sphere((0, 0, 0), 1.0), S.Material.new_matte(S.Color(0.8, 0.6, 0.4), 20.0)))
+    cam = S.Camera.perspective(S.Film(24, 16), (0, 1, -6), (0, 0.5, 0), (0, 1, 0), 50)
+    sc = S.Scene(4, 4, cam, [], prims)
+    ctx = backend.Context(0)
+    host = backend.HostScene(sc, bvh_ctx=ctx)
+    assert len(host.bvh()[0]) == (1 if n_prims == 1 else 3)
+    dev = ctx.upload(host)
+    g, gst = dev.render(seed=2, count_traversal=True)
+    o, ost = ol.OracleScene(sc).render(seed=2)
+    assert np.array_equal(g, o.astype(np.float32))
+    for k in ('closest_rays', 'shadow_rays', 'closest_nodes', 'closest_prims', 'shadow_nodes', 'shadow_prims'):
+        assert gst[k] == ost[k], k
+    assert np.array_equal(dev.render(seed=2)[0], g)
+    dev.close()
+    ctx.close()
