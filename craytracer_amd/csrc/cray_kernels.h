@@ -406,30 +406,47 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
         uint32_t p = 0;
         if (i < n) {
             p = queue ? queue[i] : i;
-            ray_t ray = mkray(mk(ps.ox[p], ps.oy[p], ps.oz[p]), mk(ps.dx[p], ps.dy[p], ps.dz[p]));
-            rgb L = mkc(ps.lr[p], ps.lg[p], ps.lb[p]);
-            rgb beta = mkc(ps.br[p], ps.bg[p], ps.bb[p]);
-            const double prev_pdf = ps.prev_pdf[p];
-            const bool specular_bounce = (ps.flags[p] & 1u) != 0;
+            // L is read and written only by the paths that add emission in this bounce (a light was hit or the ray
+            // escaped to an Infinite light); for all others the 48 B of traffic per path are skipped
+            rgb L = mkc(0, 0, 0);
+            bool L_loaded = false;
+            auto add_L = [&](rgb term) {
+                if (!L_loaded) { L = mkc(ps.lr[p], ps.lg[p], ps.lb[p]); L_loaded = true; }
+                L = L + term;
+            };
             const int32_t hp = ps.hprim[p];
-            const vec3 w_o = flip(ray.d);
+            // path state is loaded where it is first needed: an escaped path needs none of it unless the scene has an
+            // Infinite light, prev_pdf / the specular flag only matter where emission is weighted
+            rgb beta = mkc(0, 0, 0);
+            double prev_pdf = 0.0;
+            bool specular_bounce = false;
 
             if (hp < 0) {
                 // escaped: Light::Le is non-black only for Infinite lights (light.rs:161-168)
+                bool state_loaded = false;
                 for (uint32_t li = 0; li < sc.n_lights; li++) {
                     const DevLight& l = sc.lights[li];
                     if (l.kind != CRAY_LIGHT_INFINITE) continue;
+                    if (!state_loaded) {
+                        beta = mkc(ps.br[p], ps.bg[p], ps.bb[p]);
+                        prev_pdf = ps.prev_pdf[p];
+                        specular_bounce = (ps.flags[p] & 1u) != 0;
+                        state_loaded = true;
+                    }
                     rgb Le = mkc(l.c[0], l.c[1], l.c[2]);
                     if (specular_bounce) {
-                        L = L + beta * Le;  // :64-67
+                        add_L(beta * Le);  // :64-67
                     } else if (!black(Le)) {  // :68-88; pdf_Li of Infinite = 1/(4 pi) (light.rs:140)
                         double light_pdf = (kInvPi / 4.0) * light_select_pdf(sc, li);
                         double w = power_heuristic(light_pdf, prev_pdf);
-                        L = L + beta * Le * w;
+                        add_L(beta * Le * w);
                     }
                 }
-                ps.lr[p] = L.r; ps.lg[p] = L.g; ps.lb[p] = L.b;
+                if (L_loaded) { ps.lr[p] = L.r; ps.lg[p] = L.g; ps.lb[p] = L.b; }
             } else {
+                const ray_t ray = mkray(mk(ps.ox[p], ps.oy[p], ps.oz[p]), mk(ps.dx[p], ps.dy[p], ps.dz[p]));
+                const vec3 w_o = flip(ray.d);
+                beta = mkc(ps.br[p], ps.bg[p], ps.bb[p]);
                 const cray_prim pr = sc.prims[hp];
                 const int32_t mat = pr.light >= 0 ? -1 : pr.material;
                 const SurfPoint sp = surface_at(sc, pr, ray, ps.ht[p], ps.hu[p], ps.hv[p], mat >= 0 && sc.materials[mat].pad_ != 0);
@@ -447,13 +464,15 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
                     const DevLight& l = sc.lights[pr.light];
                     rgb Le = mkc(l.c[0], l.c[1], l.c[2]);
                     if (!black(Le)) {
+                        specular_bounce = (ps.flags[p] & 1u) != 0;
                         if (specular_bounce) {
-                            L = L + beta * Le;
+                            add_L(beta * Le);
                         } else {
                             double lp = light_shape_pdf_from(sc, l, x, n_s, w_o);
                             double light_pdf = lp * light_select_pdf(sc, (uint32_t)sc.first_equal_light[pr.light]);
+                            prev_pdf = ps.prev_pdf[p];
                             double w = power_heuristic(light_pdf, prev_pdf);
-                            L = L + beta * Le * w;
+                            add_L(beta * Le * w);
                         }
                     }
                 }
@@ -558,7 +577,7 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
                     // the loop condition of the next iteration (:54)
                     go = (bounce + 1 < sc.max_depth) && !black(beta);
                 }
-                ps.lr[p] = L.r; ps.lg[p] = L.g; ps.lb[p] = L.b;
+                if (L_loaded) { ps.lr[p] = L.r; ps.lg[p] = L.g; ps.lb[p] = L.b; }
                 if (go) {
                     ps.ox[p] = x.x; ps.oy[p] = x.y; ps.oz[p] = x.z;  // Ray::new(location, w_i): no offset
                     ps.dx[p] = ls.w_i.x; ps.dy[p] = ls.w_i.y; ps.dz[p] = ls.w_i.z;
