@@ -317,11 +317,10 @@ __global__ void __launch_bounds__(kBlock) k_raygen(DevScene sc, PathState ps, co
         ray_t r = camera_ray(sc, u[0], u[1], u[2], u[3], x, y);
         ps.ox[p] = r.o.x; ps.oy[p] = r.o.y; ps.oz[p] = r.o.z;
         ps.dx[p] = r.d.x; ps.dy[p] = r.d.y; ps.dz[p] = r.d.z;
-        ps.br[p] = 1.0; ps.bg[p] = 1.0; ps.bb[p] = 1.0;
+        // beta = WHITE, prev_bsdf_pdf = 0 and is_specular_bounce = true (path_integrator.rs:44-52) are not stored:
+        // k_shade knows them for bounce 0
         ps.lr[p] = 0.0; ps.lg[p] = 0.0; ps.lb[p] = 0.0;
-        ps.prev_pdf[p] = 0.0;
         ps.hash[p] = h;
-        ps.flags[p] = 1u;  // is_specular_bounce = true for camera rays (path_integrator.rs:50)
     }
 }
 
@@ -428,9 +427,9 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
                     const DevLight& l = sc.lights[li];
                     if (l.kind != CRAY_LIGHT_INFINITE) continue;
                     if (!state_loaded) {
-                        beta = mkc(ps.br[p], ps.bg[p], ps.bb[p]);
-                        prev_pdf = ps.prev_pdf[p];
-                        specular_bounce = (ps.flags[p] & 1u) != 0;
+                        beta = bounce == 0 ? mkc(1, 1, 1) : mkc(ps.br[p], ps.bg[p], ps.bb[p]);
+                        prev_pdf = bounce == 0 ? 0.0 : ps.prev_pdf[p];
+                        specular_bounce = bounce == 0 || (ps.flags[p] & 1u) != 0;
                         state_loaded = true;
                     }
                     rgb Le = mkc(l.c[0], l.c[1], l.c[2]);
@@ -446,7 +445,7 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
             } else {
                 const ray_t ray = mkray(mk(ps.ox[p], ps.oy[p], ps.oz[p]), mk(ps.dx[p], ps.dy[p], ps.dz[p]));
                 const vec3 w_o = flip(ray.d);
-                beta = mkc(ps.br[p], ps.bg[p], ps.bb[p]);
+                beta = bounce == 0 ? mkc(1, 1, 1) : mkc(ps.br[p], ps.bg[p], ps.bb[p]);  // camera rays: beta = WHITE
                 const cray_prim pr = sc.prims[hp];
                 const int32_t mat = pr.light >= 0 ? -1 : pr.material;
                 const SurfPoint sp = surface_at(sc, pr, ray, ps.ht[p], ps.hu[p], ps.hv[p], mat >= 0 && sc.materials[mat].pad_ != 0);
@@ -464,13 +463,13 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
                     const DevLight& l = sc.lights[pr.light];
                     rgb Le = mkc(l.c[0], l.c[1], l.c[2]);
                     if (!black(Le)) {
-                        specular_bounce = (ps.flags[p] & 1u) != 0;
+                        specular_bounce = bounce == 0 || (ps.flags[p] & 1u) != 0;  // camera rays count as specular (:50)
                         if (specular_bounce) {
                             add_L(beta * Le);
                         } else {
                             double lp = light_shape_pdf_from(sc, l, x, n_s, w_o);
                             double light_pdf = lp * light_select_pdf(sc, (uint32_t)sc.first_equal_light[pr.light]);
-                            prev_pdf = ps.prev_pdf[p];
+                            prev_pdf = ps.prev_pdf[p];  // bounce > 0 here
                             double w = power_heuristic(light_pdf, prev_pdf);
                             add_L(beta * Le * w);
                         }
