@@ -82,6 +82,8 @@ def main():
     dist_backend = os.environ.get('CRAY_BENCH_BACKEND', 'nccl')
     if dist_backend != 'nccl':
         local_rank = local_rank % torch.cuda.device_count()
+    elif local_rank >= torch.cuda.device_count():
+        local_rank = 0  # the launcher narrowed the visible devices to one per process
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
