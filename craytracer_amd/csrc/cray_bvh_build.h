@@ -51,7 +51,8 @@ struct SmallRec {  // node of a phase-S subtree, local DFS order at pool[2 * roo
 struct Slot {  // scratch of one active phase-L node
     unsigned long long bkey[6];  // bounds: min-keys of lo, max-keys of hi
     unsigned long long ckey[6];  // centroid bounds
-    unsigned long long bk[kBk][6];
+    unsigned long long bk[kBk][6];  // per SAH bucket: bounds of its primitives
+    unsigned long long ck[kBk][6];  // per SAH bucket: bounds of their centroids (the children's centroid bounds come from these)
     unsigned int bc[kBk];
     double c_lo, c_hi, total_area;
     int32_t axis, best;
@@ -126,10 +127,13 @@ __global__ void k_init(uint32_t* order, int32_t* slot_of, uint32_t n, int32_t ro
     if (i < n) { order[i] = i; slot_of[i] = root_slot; }
 }
 
-__device__ __forceinline__ void slot_reset(Slot& s, uint32_t node) {
-    for (int k = 0; k < 3; k++) { s.bkey[k] = ~0ull; s.bkey[3 + k] = 0ull; s.ckey[k] = ~0ull; s.ckey[3 + k] = 0ull; }
+// bkey / ckey of the root are reduced from the primitives (k_bounds); every other node gets them from its parent's
+// buckets in k_children, so this only resets them when asked to
+__device__ __forceinline__ void slot_reset(Slot& s, uint32_t node, bool reset_bounds) {
+    if (reset_bounds)
+        for (int k = 0; k < 3; k++) { s.bkey[k] = ~0ull; s.bkey[3 + k] = 0ull; s.ckey[k] = ~0ull; s.ckey[3 + k] = 0ull; }
     for (int b = 0; b < kBk; b++) {
-        for (int k = 0; k < 3; k++) { s.bk[b][k] = ~0ull; s.bk[b][3 + k] = 0ull; }
+        for (int k = 0; k < 3; k++) { s.bk[b][k] = ~0ull; s.bk[b][3 + k] = 0ull; s.ck[b][k] = ~0ull; s.ck[b][3 + k] = 0ull; }
         s.bc[b] = 0;
     }
     s.node = node;
@@ -139,7 +143,7 @@ __global__ void k_root(TopNode* top, Slot* slots, uint32_t* active, uint32_t* sm
     TopNode t{};
     t.begin = 0; t.end = n; t.lefts = 0; t.left = t.right = -1;
     ctl->n_top = 1; ctl->error = 0; ctl->n_next = 0;
-    if (n > kSmall) { t.slot = 0; active[0] = 0; slot_reset(slots[0], 0); ctl->n_small = 0; }
+    if (n > kSmall) { t.slot = 0; active[0] = 0; slot_reset(slots[0], 0, true); ctl->n_small = 0; }
     else { t.slot = -1; small_list[0] = 0; ctl->n_small = 1; }
     top[0] = t;
 }
@@ -207,7 +211,7 @@ __global__ void k_setup(TopNode* top, Slot* slots, uint32_t n_active, Ctl* ctl) 
 // SAH buckets of every active node (bvh.rs:266-281); remembers each primitive's bucket for the partition
 __global__ void __launch_bounds__(kTB) k_buckets(const double* __restrict__ box, const uint32_t* __restrict__ order,
                                                  const int32_t* __restrict__ slot_of, Slot* slots, uint8_t* __restrict__ bidx, uint32_t n) {
-    __shared__ unsigned long long l_key[kBk][6];
+    __shared__ unsigned long long l_key[kBk][6], l_ckey[kBk][6];
     __shared__ unsigned int l_cnt[kBk];
     const uint32_t base = blockIdx.x * kTB, pos = base + threadIdx.x;
     const uint32_t last = base + kTB - 1 < n - 1 ? base + kTB - 1 : n - 1;
@@ -217,22 +221,29 @@ __global__ void __launch_bounds__(kTB) k_buckets(const double* __restrict__ box,
     if (!uniform && s < 0) return;
     if (uniform && !__syncthreads_or(s >= 0)) return;
     int b = 0;
-    unsigned long long key[6];
+    unsigned long long key[6], ckey[3];
     if (s >= 0) {
         const Slot& sl = slots[s];
         const double* bx = box + 6 * (size_t)order[pos];
         const int axis = sl.axis;
-        const double c = (bx[axis] + bx[3 + axis]) * 0.5;
-        b = bucket_of(c, sl.c_lo, sl.c_hi);
+        double cen[3];
+        for (int k = 0; k < 3; k++) { cen[k] = (bx[k] + bx[3 + k]) * 0.5; ckey[k] = enc(cen[k]); }
+        b = bucket_of(cen[axis], sl.c_lo, sl.c_hi);
         bidx[pos] = (uint8_t)b;
         for (int k = 0; k < 6; k++) key[k] = enc(bx[k]);
     }
     if (uniform) {
-        if (threadIdx.x < kBk * 6) l_key[threadIdx.x / 6][threadIdx.x % 6] = (threadIdx.x % 6) < 3 ? ~0ull : 0ull;
+        if (threadIdx.x < kBk * 6) {
+            l_key[threadIdx.x / 6][threadIdx.x % 6] = (threadIdx.x % 6) < 3 ? ~0ull : 0ull;
+            l_ckey[threadIdx.x / 6][threadIdx.x % 6] = (threadIdx.x % 6) < 3 ? ~0ull : 0ull;
+        }
         if (threadIdx.x < kBk) l_cnt[threadIdx.x] = 0;
         __syncthreads();
         if (s >= 0) {
-            for (int k = 0; k < 3; k++) { atomicMin(&l_key[b][k], key[k]); atomicMax(&l_key[b][3 + k], key[3 + k]); }
+            for (int k = 0; k < 3; k++) {
+                atomicMin(&l_key[b][k], key[k]); atomicMax(&l_key[b][3 + k], key[3 + k]);
+                atomicMin(&l_ckey[b][k], ckey[k]); atomicMax(&l_ckey[b][3 + k], ckey[k]);
+            }
             atomicAdd(&l_cnt[b], 1u);
         }
         __syncthreads();
@@ -240,13 +251,17 @@ __global__ void __launch_bounds__(kTB) k_buckets(const double* __restrict__ box,
             const int bb = threadIdx.x / 6, k = threadIdx.x % 6;
             if (l_cnt[bb]) {
                 Slot& sl = slots[s_first];
-                if (k < 3) atomicMin(&sl.bk[bb][k], l_key[bb][k]); else atomicMax(&sl.bk[bb][k], l_key[bb][k]);
+                if (k < 3) { atomicMin(&sl.bk[bb][k], l_key[bb][k]); atomicMin(&sl.ck[bb][k], l_ckey[bb][k]); }
+                else { atomicMax(&sl.bk[bb][k], l_key[bb][k]); atomicMax(&sl.ck[bb][k], l_ckey[bb][k]); }
                 if (k == 0) atomicAdd(&sl.bc[bb], l_cnt[bb]);
             }
         }
     } else {
         Slot& sl = slots[s];
-        for (int k = 0; k < 3; k++) { atomicMin(&sl.bk[b][k], key[k]); atomicMax(&sl.bk[b][3 + k], key[3 + k]); }
+        for (int k = 0; k < 3; k++) {
+            atomicMin(&sl.bk[b][k], key[k]); atomicMax(&sl.bk[b][3 + k], key[3 + k]);
+            atomicMin(&sl.ck[b][k], ckey[k]); atomicMax(&sl.ck[b][3 + k], ckey[k]);
+        }
         atomicAdd(&sl.bc[b], 1u);
     }
 }
@@ -376,7 +391,20 @@ __global__ void k_children(TopNode* top, Slot* slots, Slot* next_slots, uint32_t
             const uint32_t sl = atomicAdd(&ctl->n_next, 1u);
             c.slot = (int32_t)sl;
             next_active[sl] = c0 + side;
-            slot_reset(next_slots[sl], c0 + side);
+            Slot& ns = next_slots[sl];
+            slot_reset(ns, c0 + side, false);
+            // the child's bounds / centroid bounds are the unions over the buckets on its side of the split:
+            // min / max of the order-preserving keys (empty buckets hold the neutral elements)
+            const Slot& ps = slots[a];
+            const int b0 = side ? ps.best + 1 : 0, b1 = side ? kBk : ps.best + 1;
+            for (int k = 0; k < 3; k++) {
+                unsigned long long blo = ~0ull, bhi = 0ull, clo = ~0ull, chi = 0ull;
+                for (int b = b0; b < b1; b++) {
+                    blo = ps.bk[b][k] < blo ? ps.bk[b][k] : blo; bhi = ps.bk[b][3 + k] > bhi ? ps.bk[b][3 + k] : bhi;
+                    clo = ps.ck[b][k] < clo ? ps.ck[b][k] : clo; chi = ps.ck[b][3 + k] > chi ? ps.ck[b][3 + k] : chi;
+                }
+                ns.bkey[k] = blo; ns.bkey[3 + k] = bhi; ns.ckey[k] = clo; ns.ckey[3 + k] = chi;
+            }
         } else {
             c.slot = -1;
             small_list[atomicAdd(&ctl->n_small, 1u)] = c0 + side;

@@ -856,7 +856,8 @@ extern "C" int cray_bvh_build_sah(cray_ctx* c, const double* prim_bounds, uint32
     while (n_active > 0) {
         if (++levels > 4096) { set_last_error("cray_bvh_build_sah: tree deeper than 4096 levels above the %u-primitive subtrees", kSmall); rc = CRAY_ERR_UNSUPPORTED; break; }
         const dim3 grid_a((n_active + kTB - 1) / kTB);
-        hipLaunchKernelGGL(k_bounds, grid_n, blk, 0, st, d_box, d_order, d_slot_of, d_slots[cur], n);
+        // only the root reduces its bounds from the primitives; below it they come from the parent's SAH buckets (k_children)
+        if (levels == 1) hipLaunchKernelGGL(k_bounds, grid_n, blk, 0, st, d_box, d_order, d_slot_of, d_slots[cur], n);
         hipLaunchKernelGGL(k_setup, grid_a, blk, 0, st, d_top, d_slots[cur], n_active, d_ctl);
         hipLaunchKernelGGL(k_buckets, grid_n, blk, 0, st, d_box, d_order, d_slot_of, d_slots[cur], d_bidx, n);
         hipLaunchKernelGGL(k_choose, grid_a, blk, 0, st, d_slots[cur], n_active, d_ctl);
