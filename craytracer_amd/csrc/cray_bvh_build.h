@@ -34,7 +34,10 @@ namespace bvhb {
 constexpr int kBk = 12;                 // NUM_BUCKETS, bvh.rs:235
 constexpr double kTravCost = 1.0 / 8.0; // TRAVERSAL_TO_INTERSECTION_COST_RATIO, bvh.rs:236
 constexpr uint32_t kMaxLeaf = 4;        // MAX_LEAF_PRIMITIVES, bvh.rs:237
-constexpr uint32_t kSmall = 64;         // subtrees up to this size are built by one thread
+#ifndef CRAY_BVH_SMALL
+#define CRAY_BVH_SMALL 64
+#endif
+constexpr uint32_t kSmall = CRAY_BVH_SMALL;  // subtrees up to this size are built by one thread
 constexpr int kTB = 256;
 
 struct TopNode {  // a node of phase L (all interior) or the root of a phase-S subtree
