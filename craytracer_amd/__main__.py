@@ -1,7 +1,7 @@
 """Command line of the MI355X backend: the reference's CLI (src/bin/craytracer.rs:321-334:
 --scene, --output, --seed) plus the film/spp/depth overrides every BASELINE config needs.
 
-    python -m craytracer_amd --scene scenes/simple.cry --output out.pfm --width 256 --height 256 --spp 16 --max-depth 4
+    python -m craytracer_amd --scene scene.cry --output out.exr --width 256 --height 256 --spp 16 --max-depth 4
 
 Output by extension like the reference's `image_buffer.save` (craytracer.rs:366-370): .exr (default, linear
 un-clamped f32 RGB), .pfm or .npy.  The preview window is out of scope.

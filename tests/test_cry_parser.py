@@ -264,15 +264,26 @@ def desc_arrays(sc):
             'lights': arr(d.lights, d.n_lights, S.LIGHT_DT)}
 
 
-def test_simple_cry_equals_programmatic_scene():
-    """scenes/simple.cry through the reader == the constructor-built stand-in used by the benchmarks."""
-    parsed = cry.load_scene_file(os.path.join(GOLDEN, 'scenes', 'simple.cry'), width=256, height=256, num_samples=16, max_depth=4)
-    built = scenes.simple(256, 256, 16, 4)
+def test_scene_file_equals_programmatic_scene():
+    """tests/golden/scenes/glass_lamp.cry through the reader == the same scene assembled with the reference's constructor
+    names (Scene::new arguments bit for bit, then the same BVH, light CDF and camera matrices)."""
+    parsed = cry.load_scene_file(os.path.join(GOLDEN, 'scenes', 'glass_lamp.cry'))
+    floor = S.Material.new_matte(S.Color(0.7, 0.72, 0.68), 0.0)
+    ball = S.Material.new_glass(S.Color(0.95, 1, 0.95), S.Color(0.7, 0.55, 0.6), 1.6)
+    bearing = S.Material.new_metal(S.Color(0.2, 0.9, 1.1), S.Color(3.9, 2.4, 2.2))
+    lamp = S.Shape.new_disk((-4, 6, 7), 90, 35, 1.5, 0.25)
+    prims = [S.Primitive.new(S.Shape.new_disk((0, 0, 4), 90, 0, 25, 0), floor),
+             S.Primitive.new(S.Shape.new_sphere((1, 1.25, 4), 1.25), ball),
+             S.Primitive.new(S.Shape.new_sphere((-2, 0.5, 2.5), 0.5), bearing),
+             S.Primitive.new_area_light(lamp, S.Light.Area(lamp, S.Color(9, 6.5, 2)))]
+    cam = S.Camera.perspective(S.Film(320, 200), (6, 4.5, -9), (0.5, 1, 3), (0, 1, 0), 38)
+    built = S.Scene(5, 32, cam, [S.Light.Infinite(S.Color(0.03, 0.06, 0.4))], prims)
     a, b = desc_arrays(parsed), desc_arrays(built)
     for k in ('spheres', 'disks', 'lights'):
         assert a[k].tobytes() == b[k].tobytes(), k
-    assert a['prims']['shape_kind'].tolist() == b['prims']['shape_kind'].tolist()
-    assert a['prims']['light'].tolist() == b['prims']['light'].tolist()
+    for col in ('shape_kind', 'shape', 'light'):   # material ids are numbered differently by the two front ends
+        assert a['prims'][col].tolist() == b['prims'][col].tolist(), col
+    assert (parsed.desc().max_depth, parsed.desc().num_samples) == (5, 32)
     ha, hb = backend.HostScene(parsed), backend.HostScene(built)
     na, ra = ha.bvh()
     nb, rb = hb.bvh()
@@ -282,8 +293,8 @@ def test_simple_cry_equals_programmatic_scene():
         assert np.array_equal(x, y)
 
 
-@pytest.mark.parametrize('name', ['test', 'materials'])
-def test_reference_scene_files_parse(name):
+@pytest.mark.parametrize('name', ['shapes_and_lights', 'material_zoo'])
+def test_scene_files_parse(name):
     sc = cry.load_scene_file(os.path.join(GOLDEN, 'scenes', name + '.cry'))
     assert sc.n_prims > 5 and sc.warnings == 0
     assert backend.HostScene(sc).flat.n_nodes > 1

@@ -1,7 +1,7 @@
-"""Reference scene files (scenes/{simple,test,materials}.cry, fixtures under tests/golden) through
-the whole product path: .cry reader -> Scene::new mirror -> GPU, against the oracle fed with the
-same parsed description.  materials.cry covers Oren-Nayar at several sigmas, four metals, four
-glasses, four plastics, a spherical area light and an Infinite light."""
+"""Scene files (tests/golden/scenes/*.cry: written for these tests in the reference's grammar) through the whole
+product path: .cry reader -> Scene::new mirror -> GPU, against the oracle fed with the same parsed description.
+material_zoo.cry covers Oren-Nayar at five sigmas, four metals, four glasses, five plastics, a spherical area light
+and an Infinite light; shapes_and_lights.cry every shape kind, a triangle area light and both delta lights."""
 import os
 
 import numpy as np
@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'scenes')
 
 
-@pytest.mark.parametrize('name,w,h,spp', [('simple', 70, 40, 8), ('test', 50, 50, 8), ('materials', 64, 42, 8)])
+@pytest.mark.parametrize('name,w,h,spp', [('glass_lamp', 70, 40, 8), ('shapes_and_lights', 50, 50, 8), ('material_zoo', 64, 42, 8)])
 def test_parsed_scene_renders_pixel_exact(name, w, h, spp):
     sc = cry.load_scene_file(os.path.join(GOLDEN, name + '.cry'), width=w, height=h, num_samples=spp)
     ctx = backend.Context(0)
@@ -36,7 +36,7 @@ def test_command_line_writes_the_same_film_as_exr(tmp_path):
     """`python -m craytracer_amd --scene .. --output out.exr` (the reference's CLI, craytracer.rs:321-370): the EXR
     on disk holds exactly the film the library returns, which is the oracle's."""
     from craytracer_amd.__main__ import main
-    path = os.path.join(GOLDEN, 'test.cry')
+    path = os.path.join(GOLDEN, 'shapes_and_lights.cry')
     out = str(tmp_path / 'out.exr')
     assert main(['--scene', path, '--output', out, '--seed', '5', '--width', '40', '--height', '30', '--spp', '4', '--max-depth', '5']) == 0
     film = backend.read_exr(out)
