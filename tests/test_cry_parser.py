@@ -1,6 +1,6 @@
 """The reference's tests/test_parser.rs re-expressed against the C++ `.cry` reader
-(include/cray_cry.h), plus OBJ/MTL ingest checks.  Fixtures under tests/golden/ are data files
-the reference's tests/scenes hold (objs/triangle.obj, scenes/{simple,test,materials}.cry)."""
+(include/cray_cry.h), plus OBJ/MTL ingest checks.  tests/golden/triangle.obj is the five-line data file the reference's
+parser test reads (test_parser.rs:587-640); the scene files under tests/golden/scenes/ were written for this repository."""
 import os
 
 import numpy as np
