@@ -187,3 +187,57 @@ def test_tiny_scenes_with_a_leaf_root_or_one_split(n_prims):
     assert np.array_equal(dev.render(seed=2)[0], g)
     dev.close()
     ctx.close()
+
+
+@pytest.mark.parametrize('name', ['cornell', 'test', 'dragon'])
+def test_adversarial_rays_bit_exact(name):
+    """Rays the slab test's corner cases are made of: axis-parallel directions (zero and negative-zero components:
+    0/0 = NaN inside the reference's min/max, and the kernel's plain-division path since the exact-FMA guard rejects
+    d = 0), origins exactly on bounding planes / vertices / inside boxes, tiny and huge max distances, denormal
+    direction components.  Hits, distances, locations, normals and the node / primitive counters must equal the oracle's."""
+    sc = dict(small_scenes())[name]
+    ctx = backend.Context(0)
+    dev = ctx.upload(backend.HostScene(sc))
+    orc = ol.OracleScene(sc)
+    nodes, _ = orc.bvh()
+    rng = np.random.default_rng(5)
+    # points of interest: corners / face centres of random BVH boxes and of the root
+    pick = nodes[rng.integers(0, len(nodes), 400)]
+    pts = [np.where(rng.random((len(pick), 3)) < 0.5, pick['bmin'], pick['bmax']),
+           (pick['bmin'] + pick['bmax']) * 0.5,
+           np.where(rng.random((len(pick), 3)) < 0.5, pick['bmin'], (pick['bmin'] + pick['bmax']) * 0.5)]
+    pts = np.concatenate(pts)
+    pts = pts[np.all(np.abs(pts) < 1e6, axis=1)]
+    dirs = []
+    for ax in range(3):
+        for sgn in (1.0, -1.0):
+            d = np.zeros(3); d[ax] = sgn; dirs.append(d)
+            d = np.zeros(3); d[ax] = sgn; d[(ax + 1) % 3] = -0.0; dirs.append(d)          # negative zero component
+            d = np.zeros(3); d[ax] = sgn; d[(ax + 2) % 3] = 5e-324; dirs.append(d)        # denormal component
+            d = np.zeros(3); d[ax] = sgn * np.sqrt(0.5); d[(ax + 1) % 3] = np.sqrt(0.5); dirs.append(d)  # in a coordinate plane
+    dirs = np.array(dirs)
+    n = len(pts)
+    rays = np.zeros((n * 3, 7))
+    for k, tmax in enumerate((np.inf, 1e-6, 3.0)):
+        rays[k * n:(k + 1) * n, :3] = pts
+        rays[k * n:(k + 1) * n, 3:6] = dirs[rng.integers(0, len(dirs), n)]
+        rays[k * n:(k + 1) * n, 6] = tmax
+    # origins pushed off the plane by one ulp in both directions
+    extra = rays[:n].copy()
+    extra[:, :3] = np.nextafter(extra[:, :3], np.where(rng.random((n, 3)) < 0.5, -np.inf, np.inf))
+    rays = np.concatenate([rays, extra])
+    g, gst = dev.trace(rays)
+    o, ost = orc.trace(rays)
+    assert np.array_equal(g['hit'], o['hit'])
+    h = o['hit'] != 0
+    assert np.array_equal(g['prim'][h], o['prim'][h])
+    for f in ('t', 'location', 'normal'):
+        assert np.array_equal(g[f][h], o[f][h]), f
+    assert gst['closest_nodes'] == ost['closest_nodes'] and gst['closest_prims'] == ost['closest_prims']
+    ga, gast = dev.trace(rays, any_hit=True)
+    oa, oast = orc.trace(rays, any_hit=True)
+    assert np.array_equal(ga['hit'], oa['hit'])
+    assert gast['shadow_nodes'] == oast['shadow_nodes'] and gast['shadow_prims'] == oast['shadow_prims']
+    assert int(h.sum()) > 20
+    dev.close()
+    ctx.close()
