@@ -241,3 +241,39 @@ def test_adversarial_rays_bit_exact(name):
     assert int(h.sum()) > 20
     dev.close()
     ctx.close()
+
+
+def test_ragged_film_and_sample_counts():
+    """Film sizes that are no multiple of the 64x64 tile, a sample count that is no multiple of the 8-sample batch,
+    and a path pool that cuts both: the film must still be the oracle's, pixel for pixel."""
+    from craytracer_amd import scenes
+    sc = scenes.test_scene(37, 23, 13, 5, with_infinite=True, with_point=True)
+    ctx = backend.Context(0)
+    dev = ctx.upload(backend.HostScene(sc))
+    o, _ = ol.OracleScene(sc).render(seed=4)
+    for pool in (0, 777, 8 * 37):
+        g, st = dev.render(seed=4, max_paths_in_flight=pool)
+        assert np.array_equal(g, o.astype(np.float32)), pool
+        assert st['paths'] == 37 * 23 * 13
+    # three ranks, ragged tiles: the shares add up to the film
+    acc = np.zeros_like(o, dtype=np.float32)
+    for r in range(3):
+        part, _ = dev.render(seed=4, rank=r, world_size=3, max_paths_in_flight=500)
+        acc += part
+    assert np.array_equal(acc, o.astype(np.float32))
+    dev.close()
+    ctx.close()
+
+
+def test_limits_are_reported_not_truncated():
+    """sobol_burley indexes 2^16 samples and 256 dimensions (max_depth <= 31): beyond that the reference's crate asserts;
+    here the calls fail with CRAY_ERR_UNSUPPORTED instead of rendering something else."""
+    from craytracer_amd import scenes
+    ctx = backend.Context(0)
+    with pytest.raises(backend.CrayError, match='dimension'):
+        ctx.upload(backend.HostScene(scenes.test_scene(8, 8, 1, 32)))
+    dev = ctx.upload(backend.HostScene(scenes.test_scene(4, 4, 70000, 2)))
+    with pytest.raises(backend.CrayError, match='2\\^16'):
+        dev.render(seed=0)
+    dev.close()
+    ctx.close()
