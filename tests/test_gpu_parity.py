@@ -277,3 +277,36 @@ def test_limits_are_reported_not_truncated():
         dev.render(seed=0)
     dev.close()
     ctx.close()
+
+
+@pytest.mark.parametrize('kind', ['orthographic', 'orthographic_lens', 'perspective_lens'])
+def test_other_cameras(kind):
+    """Camera::orthographic and the square thin lens (camera.rs:100-162) on a non-square film (the reference's
+    `film_height = film.width` quirk shifts the principal point): film and camera matrices equal the oracle's."""
+    from craytracer_amd import scene as S
+    s_light = S.Shape.new_sphere((3, 4, -2), 1.0)
+    tex = S.Texture.checkerboard(S.Color(0.9, 0.9, 0.9), S.Color(0.2, 0.3, 0.8), 3.0)
+    prims = [S.Primitive.new_area_light(s_light, S.Light.Area(s_light, S.Color(6, 6, 6))),
+             S.Primitive.new(S.Shape.new_disk((0, 0, 0), 90, 0, 6, 0), S.Material.new_matte(tex, 0.0)),
+             S.Primitive.new(S.Shape.new_sphere((-1, 1, 0), 1.0), S.Material.new_plastic(S.Color(0.8, 0.3, 0.2), S.Color(1, 1, 1), 20.0)),
+             S.Primitive.new(S.Shape.new_triangle((1, 0, 1), (2.5, 0, 1), (1, 2, 1)), S.Material.new_metal(S.Color(0.2, 0.9, 1.1), S.Color(3.9, 2.4, 2.2)))]
+    film = S.Film(40, 24)
+    if kind == 'orthographic':
+        cam = S.Camera.orthographic(film, (0, 6, -6), (0, 0.5, 0), (0, 1, 0))
+    elif kind == 'orthographic_lens':
+        cam = S.Camera.orthographic(film, (0, 6, -6), (0, 0.5, 0), (0, 1, 0), lens_radius=0.05, focal_distance=8.0)
+    else:
+        cam = S.Camera.perspective(film, (0, 3, -7), (0, 0.5, 0), (0, 1, 0), 40, lens_radius=0.08, focal_distance=7.0)
+    sc = S.Scene(5, 8, cam, [S.Light.Distant((0.3, -1, 0.2), S.Color(0.5, 0.5, 0.5))], prims)
+    ctx = backend.Context(0)
+    host = backend.HostScene(sc, bvh_ctx=ctx)
+    orc = ol.OracleScene(sc)
+    for a, b in zip(host.camera_matrices(), orc.camera_matrices()):
+        assert np.array_equal(a, b)
+    dev = ctx.upload(host)
+    g, _ = dev.render(seed=6)
+    o, _ = orc.render(seed=6)
+    assert np.array_equal(g, o.astype(np.float32))
+    assert float(g.mean()) > 1e-3
+    dev.close()
+    ctx.close()
