@@ -70,3 +70,22 @@ def test_random_paths_of_all_samples_against_oracle(full):
         for _ in range(150):
             x, y, j = int(rng.integers(0, 1920)), int(rng.integers(0, 1080)), int(rng.integers(0, 8))
             assert np.array_equal(L[y, x, j], orc.render_pixel(x, y, s0 + j, seed=0)), (x, y, s0 + j)
+
+
+def test_final_pixels_of_the_64_spp_frame_against_oracle(full):
+    """Whole pixels of the full frame, film accumulation included: per pixel the oracle's 64 path radiances are summed
+    the way the reference's render_tile does it (f64 sum of each 8-sample batch -> f32 add, craytracer.rs:175-188),
+    divided by num_samples in f32 (:253-259) — and must equal the GPU film bit for bit."""
+    sc, host, dev, orc = full
+    film, _ = dev.render(seed=0)
+    rng = np.random.default_rng(7)
+    pixels = [(960, 540), (1000, 620), (700, 500)] + [(int(rng.integers(0, 1920)), int(rng.integers(0, 1080))) for _ in range(9)]
+    for x, y in pixels:
+        acc = np.zeros(3, dtype=np.float32)
+        for b0 in range(0, 64, 8):
+            c = np.zeros(3, dtype=np.float64)
+            for s in range(b0, b0 + 8):
+                c = c + orc.render_pixel(x, y, s, seed=0)
+            acc = acc + c.astype(np.float32)
+        expect = acc / np.float32(64)
+        assert np.array_equal(film[y, x], expect), (x, y, film[y, x], expect)
