@@ -4,14 +4,18 @@
 A "step" is one whole frame of the hot path: every path of the frame goes through
 raygen -> {trace_closest, shade, trace_any} x max_depth -> film, with the scene already resident in
 HBM.  At N GPUs the SAME frame is sharded by 64x64 pixel tile (tile % N == rank) and rank 0 gathers
-the Film tiles over RCCL (strong scaling, as the north star defines it).
+the Film tiles over RCCL (strong scaling, as the north star defines it) — through the C ABI
+(cray_comm_init / cray_scene_broadcast / cray_render_gather, include/cray.h): the path a Rust or C host
+takes, with no torch.distributed process group.  torch is used for the stream, the pinned host film and (N > 1)
+the launcher's rendezvous store that carries the 128-byte communicator id.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel family (BVH traversal, k_trace*):
-algorithmic bytes / HIP-event time of those launches over the timed steps.  `cpu_baseline`
+algorithmic bytes / HIP-event time of those launches over the timed steps, next to the HBM bytes
+the PMC counters saw (profiles/hbm_traffic.json, from separate rocprofv3 --pmc passes).  `cpu_baseline`
 is the CPU oracle (a C++ restatement of the reference path; the Rust reference cannot be built
 here) on a bounded sample of the same workload.
 """
@@ -29,6 +33,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 # algorithmic bytes of the f64 layout (DESIGN.md "Algorithmic bytes")
 B_NODE, B_TRI, B_OTHER, B_RAY = 64, 72, 48, 88
+# k_shade, per unit: a shaded path reads queue entry + hit primitive id (8 B); a path that hit something
+# also reads its ray, hit record, beta, Sobol seed, primitive and shading record and (emitters, escapes aside) goes on:
+B_SHADE_IN, B_SHADE_HIT = 8, 48 + 24 + 24 + 4 + 16 + 120
+B_SHADE_SHADOW = 56 + 24 + 4          # a stored shadow ray: origin/direction/tmax + gated NEE term + queue entry
+B_SHADE_NEXT = 48 + 24 + 8 + 4 + 4    # a continued path: new ray, beta, prev pdf, flags + queue entry
 
 WORKLOADS = {
     # name: scene factory kwargs + 'scene' (factory in craytracer_amd.scenes) + 'label' (which BASELINE.json config it is)
@@ -56,6 +65,23 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def exchange_comm_id(backend, rank, world):
+    """Rank 0 creates the RCCL unique id; the launcher's rendezvous store (torchrun's c10d TCP store at
+    MASTER_ADDR:MASTER_PORT) carries its 128 bytes to the other ranks.  No process group is created."""
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29500')
+    from torch.distributed import rendezvous
+    store, _, _ = next(rendezvous('env://', rank=rank, world_size=world))
+    key = 'cray_comm_id'
+    if rank == 0:
+        cid = backend.Context.comm_unique_id()
+        store.set(key, cid)
+    else:
+        cid = bytes(store.get(key))   # blocks until rank 0 has set it
+    assert len(cid) == 128
+    return cid, store
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -65,11 +91,12 @@ def main():
     ap.add_argument('--cpu-baseline', type=int, default=1)
     ap.add_argument('--count-pass', type=int, default=1)
     ap.add_argument('--host-bvh', type=int, default=0, help='1: build the BVH on the host instead of the GPU')
+    ap.add_argument('--replicate-host', type=int, default=0,
+                    help='N > 1: 1 = every rank builds and uploads the scene itself instead of cray_scene_broadcast from rank 0')
     args = ap.parse_args()
 
     import numpy as np
     import torch
-    import torch.distributed as dist
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -77,57 +104,60 @@ def main():
     if world != args.gpus:
         log('warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE' % (world, args.gpus))
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the backend has no CPU fallback)'
-    # One process per GPU over RCCL.  CRAY_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than
-    # ranks (ranks then share GPUs and the tile gather is staged through the host); never used for reported numbers.
-    dist_backend = os.environ.get('CRAY_BENCH_BACKEND', 'nccl')
-    if dist_backend != 'nccl':
-        local_rank = local_rank % torch.cuda.device_count()
-    elif local_rank >= torch.cuda.device_count():
+    if local_rank >= torch.cuda.device_count():
         local_rank = 0  # the launcher narrowed the visible devices to one per process
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if dist_backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
-        else:
-            dist.init_process_group(dist_backend, rank=rank, world_size=world)
 
     from craytracer_amd import backend, scenes
-    from craytracer_amd import dist as cdist
+    from craytracer_amd import build as hip_build
 
-    wl = WORKLOADS[args.workload]
-    t0 = time.time()
-    scene = make_scene(scenes, args.workload)
-    W, H = scene.film_bounds()
-    t1 = time.time()
     stream = torch.cuda.current_stream()
     ctx = backend.Context(local_rank, stream=stream.cuda_stream)
-    # Scene::new (untimed by the metric): LightSampler/Camera on the host, Bvh::new on the GPU (same tree)
-    host = backend.HostScene(scene, bvh_ctx=None if args.host_bvh else ctx)
-    t2 = time.time()
-    dev = ctx.upload(host)
-    torch.cuda.synchronize()
-    t3 = time.time()
-    if rank == 0:
-        log('scene: %d triangles, %d BVH nodes; generate %.1fs, Scene::new %.1fs (Bvh::new %.2fs, %s), upload %.1fs (%.2f GB in HBM)'
-            % (len(scene.triangles), host.flat.n_nodes, t1 - t0, t2 - t1, host.bvh_seconds,
-               'host' if args.host_bvh else 'GPU kernels %.3fs' % host.gpu_build['device_seconds'], t3 - t2, dev.device_bytes / 1e9))
+    store = None
+    if world > 1:
+        cid, store = exchange_comm_id(backend, rank, world)
+        ctx.comm_init(cid, rank, world)   # ncclCommInitRank: one rank per GPU over RCCL / xGMI
+        ctx.barrier()
 
-    film = torch.zeros((H, W, 3), dtype=torch.float32, device='cuda')
+    wl = WORKLOADS[args.workload]
+    W, H = wl['width'], wl['height']
+    scene = host = dev = None
+    t0 = time.time()
+    builds_scene = rank == 0 or args.replicate_host
+    if builds_scene:
+        scene = make_scene(scenes, args.workload)
+        t1 = time.time()
+        # Scene::new (untimed by the metric): LightSampler/Camera on the host, Bvh::new on the GPU (same tree)
+        host = backend.HostScene(scene, bvh_ctx=None if args.host_bvh else ctx)
+        t2 = time.time()
+        dev = ctx.upload(host)
+        torch.cuda.synchronize()
+        t3 = time.time()
+        if rank == 0:
+            log('scene: %d triangles, %d BVH nodes; generate %.1fs, Scene::new %.1fs (Bvh::new %.2fs, %s), upload %.1fs (%.2f GB in HBM)'
+                % (len(scene.triangles), host.flat.n_nodes, t1 - t0, t2 - t1, host.bvh_seconds,
+                   'host' if args.host_bvh else 'GPU kernels %.3fs' % host.gpu_build['device_seconds'], t3 - t2, dev.device_bytes / 1e9))
+    if world > 1 and not args.replicate_host:
+        tb = time.time()
+        dev = ctx.broadcast_scene(dev, root=0)   # rank 0's HBM -> every rank's HBM over xGMI (C1)
+        if rank == 0:
+            log('scene broadcast to %d ranks: %.2f s' % (world, time.time() - tb))
+    assert (dev.width, dev.height) == (W, H)
+
+    # Film resident on the rank-0 host, like the Vec<f32> handed to on_render_finish (pinned, so the copy out of the
+    # device is one asynchronous DMA)
     host_film = torch.empty((H, W, 3), dtype=torch.float32).pin_memory() if rank == 0 else None
+    host_np = host_film.numpy() if rank == 0 else None
 
     def frame():
-        _, st = dev.render(seed=0, rank=rank, world_size=world, out_device_ptr=film.data_ptr())
-        out = cdist.gather_film(film, W, H, rank, world)
-        if rank == 0:
-            # Film resident on the rank-0 host, like the Vec<f32> handed to on_render_finish
-            host_film.copy_(out, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
-        return st, host_film
+        if world > 1:
+            _, st = dev.render_gather(seed=0, out=host_np)
+        else:
+            _, st = dev.render(seed=0, out=host_np)
+        return st
 
     def barrier():
-        if world > 1:
-            dist.barrier()
+        ctx.barrier()               # all-reduce over RCCL + stream sync (a stream sync alone when N = 1)
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -135,24 +165,20 @@ def main():
     barrier()
     t_start = time.perf_counter()
     stats = []
-    out = None
     for _ in range(args.steps):
-        st, out = frame()
-        stats.append(st)
+        stats.append(frame())
     barrier()
     elapsed = time.perf_counter() - t_start
-    el = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-    rays = torch.tensor([float(sum(s['closest_rays'] + s['shadow_rays'] - s['shadow_skipped'] for s in stats))], dtype=torch.float64, device='cuda')
-    trace_ms = sum(s['trace_closest_ms'] + s['trace_mixed_ms'] + s['trace_any_ms'] for s in stats)
-    trace_launches = sum(s['trace_closest_launches'] + s['trace_mixed_launches'] + s['trace_any_launches'] for s in stats)
-    kern = torch.tensor([trace_ms, float(trace_launches), sum(s['trace_closest_ms'] for s in stats), sum(s['trace_mixed_ms'] for s in stats),
-                         sum(s['trace_any_ms'] for s in stats), sum(s['shade_ms'] for s in stats), sum(s['other_ms'] for s in stats)],
-                        dtype=torch.float64, device='cuda')
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
-    elapsed = float(el.item())
-    total_rays = float(rays.item())
+    elapsed = float(ctx.allreduce([elapsed], 'max')[0])   # MAX over ranks
+    sums = [float(sum(s['closest_rays'] + s['shadow_rays'] - s['shadow_skipped'] for s in stats)),
+            float(sum(s['closest_rays'] + s['shadow_rays'] for s in stats)),
+            float(sum(s['paths'] for s in stats))]
+    total_rays, total_queries, total_paths = (float(v) for v in ctx.allreduce(sums, 'sum'))
+    kern = [sum(s['trace_closest_ms'] + s['trace_mixed_ms'] + s['trace_any_ms'] for s in stats),
+            float(sum(s['trace_closest_launches'] + s['trace_mixed_launches'] + s['trace_any_launches'] for s in stats)),
+            sum(s['trace_closest_ms'] for s in stats), sum(s['trace_mixed_ms'] for s in stats),
+            sum(s['trace_any_ms'] for s in stats), sum(s['shade_ms'] for s in stats), sum(s['other_ms'] for s in stats),
+            float(sum(s['shade_launches'] for s in stats))]
 
     # --- roofline of the dominant kernel family: BVH traversal (k_trace<closest> for bounce 0, k_trace_mixed =
     # shadow rays of bounce b + segments of bounce b+1, k_trace<any> for the last bounce), this rank's share.
@@ -161,44 +187,61 @@ def main():
     roofline = None
     counts = None
     if args.count_pass:
-        _, cst = dev.render(seed=0, rank=rank, world_size=world, out_device_ptr=film.data_ptr(), count_traversal=2)
+        film_dev = torch.zeros((H, W, 3), dtype=torch.float32, device='cuda')
+        _, cst = dev.render(seed=0, rank=rank, world_size=world, out_device_ptr=film_dev.data_ptr(), count_traversal=2)
+        del film_dev
         counts = cst
         tri = cst['closest_tri_tests'] + cst['shadow_tri_tests']
         other = cst['closest_prims'] + cst['shadow_prims'] - tri
         nodes = cst['closest_nodes'] + cst['shadow_nodes']
         traced = cst['closest_rays'] + cst['shadow_rays'] - cst['shadow_skipped']
         alg_bytes_frame = B_NODE * nodes + B_TRI * tri + B_OTHER * other + B_RAY * traced
-        k_ms, k_launches = float(kern[0].item()), float(kern[1].item())
+        k_ms, k_launches = kern[0], kern[1]
         launches_per_frame = k_launches / max(1, args.steps)
         avg_ms = k_ms / max(1.0, k_launches)
         achieved = (alg_bytes_frame * args.steps) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        traffic = None
+        # HBM bytes the PMC counters saw for these kernels: NOT measured by this run (counters need their own rocprofv3
+        # --pmc passes); taken from the committed summary, whose provenance travels with the number
+        traffic, provenance = None, None
         tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and world == 1:
             try:
-                traffic = json.load(open(tpath)).get(args.workload, {}).get('trace_bytes_per_launch')
+                ent = json.load(open(tpath)).get(args.workload, {})
+                traffic = ent.get('trace_bytes_per_launch')
+                provenance = {'file': 'profiles/hbm_traffic.json', 'pmc_csv': ent.get('source'), 'profiled_build': ent.get('git'),
+                              'method': 'FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 from separate rocprofv3 --pmc passes (tools/traffic_from_pmc.py)'}
             except Exception:
                 traffic = None
-        roofline = {'bound': 'hbm', 'kernel': 'k_trace family (k_trace<closest> + k_trace_mixed + k_trace<any>)', 'achieved': round(achieved, 2),
+        roofline = {'bound': 'hbm',
+                    'bound_note': 'north_star prices this path against the HBM roofline; the PMC counters show the kernel is limited by '
+                                  'dependent L2/TA fetch latency and f64 VALU issue, not by HBM bandwidth (hbm_counter_frac; DESIGN.md §3.1)',
+                    'kernel': 'k_trace family (k_trace<closest> + k_trace_mixed + k_trace<any>)', 'achieved': round(achieved, 2),
                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
+                    'traffic_provenance': provenance,
+                    'hbm_counter_GBs': round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic and avg_ms > 0 else None,
+                    'hbm_counter_frac': round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic and avg_ms > 0 else None,
                     'alg_bytes_per_launch': round(alg_bytes_frame / max(1.0, launches_per_frame)),
                     'avg_launch_ms': round(avg_ms, 4), 'launches_per_step': launches_per_frame,
                     'bytes_per_ray': round(alg_bytes_frame / max(1, traced), 1)}
+        # the second kernel of the frame: k_shade (path state + shading records)
+        n_shaded = cst['closest_rays']                      # every traced segment is shaded once
+        n_hit = cst.get('closest_hits', 0) or n_shaded      # segments that hit something
+        n_shadow = cst['shadow_rays'] - cst['shadow_skipped']
+        n_next = cst['closest_rays'] - cst['paths']          # segments of bounce >= 1 = paths continued by k_shade
+        shade_bytes = B_SHADE_IN * n_shaded + B_SHADE_HIT * n_hit + B_SHADE_SHADOW * n_shadow + B_SHADE_NEXT * n_next
+        shade_ms, shade_launches = kern[5], kern[7]
+        if shade_ms > 0:
+            sh = shade_bytes * args.steps / (shade_ms * 1e-3) / 1e9
+            roofline['k_shade'] = {'achieved': round(sh, 2), 'unit': 'GB/s', 'frac': round(sh / HBM_PEAK_GBS, 5),
+                                   'alg_bytes_per_launch': round(shade_bytes * args.steps / max(1.0, shade_launches)),
+                                   'avg_launch_ms': round(shade_ms / max(1.0, shade_launches), 4),
+                                   'launches_per_step': shade_launches / max(1, args.steps)}
 
     # --- what a plain streaming read reaches on this very GPU (SURVEY.md §8d asks for the roofline against the
-    # measured figure next to the 8 TB/s spec): torch.sum over 4 GiB of f32, HIP events on the current stream
+    # measured figure next to the 8 TB/s spec): a 16-B/lane read kernel over 4 GiB (cray_measure_stream_read)
     if roofline is not None and rank == 0:
         try:
-            big = torch.empty(1 << 30, dtype=torch.float32, device='cuda').fill_(1.0)
-            torch.sum(big)
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record()
-            for _ in range(5):
-                torch.sum(big)
-            ev1.record()
-            torch.cuda.synchronize()
-            stream_gbs = 5 * big.numel() * 4 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
-            del big
+            stream_gbs = ctx.measure_stream_read(4 << 30, 5)
             roofline['measured_stream_read_GBs'] = round(stream_gbs, 1)
             roofline['frac_of_measured_stream'] = round(roofline['achieved'] / stream_gbs, 5)
         except Exception as e:  # measurement aid only
@@ -209,40 +252,48 @@ def main():
     if rank == 0 and world == 1 and args.cpu_baseline:
         from oracle import oracle_lib
         tb = time.time()
+        oracle_lib.set_libm_mode(1)   # the platform libm's sin/cos, like the reference binary (not the binary128 checker mode)
         orc = oracle_lib.OracleScene(scene)
         cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
         _, ost = orc.render(seed=0, threads=cores, sample_range=(0, 1))
+        oracle_lib.set_libm_mode(0)
         cpu_rays = ost['closest_rays'] + ost['shadow_rays']
         cpu = {'value': round(cpu_rays / ost['seconds'] / 1e6, 3), 'unit': 'Mray/s', 'cores': cores, 'kind': 'port',
-               'sample': '1 of %d spp of the same %dx%d frame (%d rays, %.1f s); C++ restatement of the reference CPU path, '
+               'sample': '1 of %d spp of the same %dx%d frame (%d rays, %.1f s); C++ restatement of the reference CPU path (-O2, glibc sin/cos), '
                          'the Rust reference is not buildable here' % (wl['spp'], W, H, cpu_rays, ost['seconds'])}
         log('cpu baseline: %.2f Mray/s on %d threads (oracle build %.1fs)' % (cpu['value'], cores, time.time() - tb - ost['seconds']))
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total_rays / elapsed / 1e6
+        n_tris = len(scene.triangles) if scene is not None else None
         line = {
             'metric': 'Mray/s (BVH queries actually traversed: Scene::intersect + Scene::intersects) on the %dx%dx%dspp %s frame' % (W, H, wl['spp'], 'dragon-class' if wl['scene'] == 'dragon' else wl['scene']),
             'value': round(value, 2), 'unit': 'Mray/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 2), 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': '%s, %d triangles, %dx%d, %d spp, depth %d'
-                                   % (wl['label'], len(scene.triangles), W, H, wl['spp'], wl['max_depth']),
-                       'parallelism': ('tile-shard x%d + RCCL gather of Film tiles' % world if dist_backend == 'nccl' else 'REHEARSAL: %d ranks sharing GPUs, gloo' % world) if world > 1 else 'single GPU',
+            'config': {'workload': '%s, %s triangles, %dx%d, %d spp, depth %d'
+                                   % (wl['label'], n_tris, W, H, wl['spp'], wl['max_depth']),
+                       'parallelism': ('tile-shard x%d; C ABI: cray_comm_init + %s + cray_render_gather (RCCL ncclSend/ncclRecv of Film tiles to rank 0)'
+                                       % (world, 'per-rank scene build' if args.replicate_host else 'cray_scene_broadcast (ncclBroadcast)')) if world > 1 else 'single GPU',
                        'seconds_per_frame': round(elapsed / args.steps, 4),
-                       'mpaths_per_s': round(W * H * wl['spp'] * args.steps / elapsed / 1e6, 2),
+                       'mpaths_per_s': round(total_paths / elapsed / 1e6, 2),
                        'rays_per_frame': int(total_rays / args.steps),
-                       'reference_queries_per_frame': int(sum(s['closest_rays'] + s['shadow_rays'] for s in stats) / args.steps) if world == 1 else None},
+                       'reference_queries_per_frame': int(total_queries / args.steps),
+                       'build': {'libcray_hip': 'stale' if hip_build.stale() else 'current', 'mode': backend.BUILD_MODE}},
             'roofline': roofline, 'cpu_baseline': cpu,
-            'kernel_ms_per_step': {'trace': round(float(kern[0].item()) / args.steps, 2), 'trace_closest_bounce0': round(float(kern[2].item()) / args.steps, 2),
-                                   'trace_mixed': round(float(kern[3].item()) / args.steps, 2), 'trace_any_last_bounce': round(float(kern[4].item()) / args.steps, 2),
-                                   'shade': round(float(kern[5].item()) / args.steps, 2), 'other': round(float(kern[6].item()) / args.steps, 2)},
+            'kernel_ms_per_step': {'trace': round(kern[0] / args.steps, 2), 'trace_closest_bounce0': round(kern[2] / args.steps, 2),
+                                   'trace_mixed': round(kern[3] / args.steps, 2), 'trace_any_last_bounce': round(kern[4] / args.steps, 2),
+                                   'shade': round(kern[5] / args.steps, 2), 'other': round(kern[6] / args.steps, 2),
+                                   'note': "rank 0's share" if world > 1 else 'whole frame'},
         }
         if counts:
             line['traversal'] = {k: counts[k] for k in ('closest_rays', 'shadow_rays', 'shadow_skipped', 'closest_nodes', 'closest_prims', 'shadow_nodes', 'shadow_prims')}
         print(json.dumps(line), flush=True)
     if world > 1:
-        dist.destroy_process_group()
+        ctx.barrier()
+    dev.close()
+    ctx.close()
 
 
 if __name__ == '__main__':

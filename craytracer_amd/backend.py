@@ -78,23 +78,38 @@ ABI_SYMBOLS = ['cray_ctx_create', 'cray_ctx_destroy', 'cray_scene_upload', 'cray
                'cray_host_scene_build_seconds', 'cray_host_scene_free', 'cray_host_scene_new_on',
                'cray_host_scene_bvh_seconds', 'cray_bvh_build_sah', 'cray_write_exr', 'cray_read_exr', 'cray_host_sincos', 'cray_host_div_fast_mismatches', 'cray_host_child_key_mismatches',
                'cray_cry_tokenize', 'cray_cry_free_tokens', 'cray_cry_parse_value', 'cray_cry_free_string',
-               'cray_cry_parse_scene', 'cray_owned_scene_desc', 'cray_owned_scene_warnings', 'cray_owned_scene_free']
+               'cray_cry_parse_scene', 'cray_owned_scene_desc', 'cray_owned_scene_warnings', 'cray_owned_scene_free',
+               'cray_scene_info', 'cray_comm_unique_id', 'cray_comm_init', 'cray_comm_rank', 'cray_comm_world_size',
+               'cray_comm_barrier', 'cray_comm_allreduce_f64', 'cray_scene_broadcast', 'cray_render_gather',
+               'cray_film_gather', 'cray_film_pack', 'cray_film_unpack', 'cray_measure_stream_read']
 
 _lib = None
+#: how the loaded library came to be: 'shipped' (the .so in the tree was current), 'rebuilt' (sources were newer, hipcc ran),
+#: 'STALE' (sources are newer than the .so and the rebuild failed: the kernels do not match the sources)
+BUILD_MODE = None
 
 
 def lib():
     """Load libcray_hip.so (building it if the sources are newer). Raises if it cannot be loaded."""
-    global _lib
+    global _lib, BUILD_MODE
     if _lib is not None:
         return _lib
     so = _build.SO
+    BUILD_MODE = 'shipped'
     if _build.stale():
         try:
             _build.build()
-        except Exception as e:  # no hipcc on this box: use the shipped .so if there is one
+            BUILD_MODE = 'rebuilt'
+        except Exception as e:  # no hipcc on this box: use the shipped .so if there is one — loudly
             if not os.path.exists(so):
                 raise CrayError('libcray_hip.so is missing and could not be built: %s' % e)
+            if os.environ.get('CRAY_ALLOW_STALE', '0') != '1':
+                raise CrayError('libcray_hip.so is older than its sources and the rebuild failed (%s); '
+                                'set CRAY_ALLOW_STALE=1 to run the stale library anyway' % e)
+            BUILD_MODE = 'STALE'
+            import sys
+            print('WARNING: libcray_hip.so is OLDER than its sources and could not be rebuilt (%s): running stale kernels' % e,
+                  file=sys.stderr, flush=True)
     try:
         L = C.CDLL(so)
     except OSError as e:
@@ -118,6 +133,21 @@ def lib():
                                      C.c_void_p, C.POINTER(BvhBuildStats)]
     L.cray_write_exr.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p]
     L.cray_read_exr.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_uint64]
+    L.cray_scene_info.restype = None
+    L.cray_scene_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint32)] * 4
+    L.cray_comm_unique_id.argtypes = [C.c_void_p]
+    L.cray_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.cray_comm_rank.argtypes = [C.c_void_p]
+    L.cray_comm_world_size.argtypes = [C.c_void_p]
+    L.cray_comm_barrier.argtypes = [C.c_void_p]
+    L.cray_comm_allreduce_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.cray_scene_broadcast.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    L.cray_render_gather.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]
+    L.cray_film_gather.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]
+    L.cray_film_pack.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
+                                 C.c_void_p, C.POINTER(C.c_uint64)]
+    L.cray_measure_stream_read.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_double)]
+    L.cray_film_unpack.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
     L.cray_host_scene_flat.restype = C.POINTER(FlatScene)
     L.cray_host_scene_flat.argtypes = [C.c_void_p]
     L.cray_host_scene_build_seconds.restype = C.c_double
@@ -212,6 +242,79 @@ class Context:
                                         refs.ctypes.data, C.byref(st)), 'cray_bvh_build_sah')
         return nodes[:n_nodes.value], refs, {k: getattr(st, k) for k, _ in BvhBuildStats._fields_}
 
+    # ---- multi-GPU (include/cray.h "multi-GPU"): one Context per rank, RCCL underneath
+    @staticmethod
+    def comm_unique_id():
+        """ncclGetUniqueId as 128 bytes: create on one rank, hand to every rank by any host channel."""
+        buf = C.create_string_buffer(128)
+        _check(lib().cray_comm_unique_id(buf), 'cray_comm_unique_id')
+        return buf.raw
+
+    def comm_init(self, comm_id, rank, world_size):
+        assert len(comm_id) == 128
+        _check(lib().cray_comm_init(self._h, C.create_string_buffer(comm_id, 128), rank, world_size), 'cray_comm_init')
+        self.rank, self.world_size = rank, world_size
+
+    def comm_rank(self):
+        return lib().cray_comm_rank(self._h)
+
+    def comm_world_size(self):
+        return lib().cray_comm_world_size(self._h)
+
+    def barrier(self):
+        _check(lib().cray_comm_barrier(self._h), 'cray_comm_barrier')
+
+    def allreduce(self, values, op='sum'):
+        """In-place all-reduce of up to 64 host doubles; returns the reduced list."""
+        v = np.ascontiguousarray(values, dtype=np.float64).copy()
+        _check(lib().cray_comm_allreduce_f64(self._h, v.ctypes.data, len(v), {'sum': 0, 'max': 1, 'min': 2}[op]),
+               'cray_comm_allreduce_f64')
+        return v
+
+    def broadcast_scene(self, device_scene=None, root=0):
+        """cray_scene_broadcast: pass the uploaded DeviceScene on `root`, None elsewhere; returns a DeviceScene."""
+        out = C.c_void_p()
+        _check(lib().cray_scene_broadcast(self._h, device_scene._h if device_scene is not None else None, root, C.byref(out)),
+               'cray_scene_broadcast')
+        if device_scene is not None:
+            return device_scene
+        return DeviceScene(self, None, handle=out)
+
+    def measure_stream_read(self, nbytes=4 << 30, repeats=5):
+        """GB/s of a plain 16-B/lane streaming read on this GPU (cray_measure_stream_read)."""
+        g = C.c_double(0.0)
+        _check(lib().cray_measure_stream_read(self._h, nbytes, repeats, C.byref(g)), 'cray_measure_stream_read')
+        return g.value
+
+    def film_pack(self, film, rank, world_size, tile=(64, 64)):
+        """Test hook: the pixels of `rank`'s tiles of a host film [H, W, 3], packed [n, 3]."""
+        f = np.ascontiguousarray(film, dtype=np.float32)
+        h, w = f.shape[:2]
+        packed = np.zeros((h * w, 3), dtype=np.float32)
+        n = C.c_uint64(0)
+        _check(lib().cray_film_pack(self._h, w, h, tile[0], tile[1], rank, world_size, f.ctypes.data, packed.ctypes.data, C.byref(n)),
+               'cray_film_pack')
+        return packed[:n.value].copy()
+
+    def film_unpack(self, gathered, width, height, world_size, tile=(64, 64)):
+        """Test hook: the rank-ordered concatenation of packed tiles [W*H, 3] -> film [H, W, 3]."""
+        g = np.ascontiguousarray(gathered, dtype=np.float32).reshape(-1, 3)
+        assert len(g) == width * height
+        out = np.zeros((height, width, 3), dtype=np.float32)
+        _check(lib().cray_film_unpack(self._h, width, height, tile[0], tile[1], world_size, g.ctypes.data, out.ctypes.data),
+               'cray_film_unpack')
+        return out
+
+    def film_gather(self, local_film_ptr, width, height, out=None, out_device_ptr=None, tile=(64, 64)):
+        """cray_film_gather: local_film_ptr = this rank's W*H*3 device film; on rank 0 fills `out` (numpy) or out_device_ptr."""
+        dst, is_dev = None, 0
+        if out_device_ptr is not None:
+            dst, is_dev = C.c_void_p(out_device_ptr), 1
+        elif out is not None:
+            dst = C.c_void_p(out.ctypes.data)
+        _check(lib().cray_film_gather(self._h, width, height, tile[0], tile[1], C.c_void_p(local_film_ptr), dst, is_dev), 'cray_film_gather')
+        return out
+
     def close(self):
         if self._h:
             lib().cray_ctx_destroy(self._h)
@@ -228,14 +331,16 @@ class DeviceScene:
     """A scene resident in HBM; `render` replaces craytracer.rs:224 `render`, `trace` replaces
     `Scene::intersect` / `Scene::intersects`."""
 
-    def __init__(self, ctx, host_scene):
+    def __init__(self, ctx, host_scene, handle=None):
         self.ctx, self.host = ctx, host_scene
-        h = C.c_void_p()
-        _check(lib().cray_scene_upload(ctx._h, C.addressof(host_scene.flat), C.byref(h)), 'cray_scene_upload')
-        self._h = h
-        self.width, self.height = host_scene.flat.film_width, host_scene.flat.film_height
-        self.num_samples = host_scene.flat.num_samples
-        self.device_bytes = lib().cray_scene_device_bytes(h)
+        if handle is None:
+            handle = C.c_void_p()
+            _check(lib().cray_scene_upload(ctx._h, C.addressof(host_scene.flat), C.byref(handle)), 'cray_scene_upload')
+        self._h = handle  # else: received by cray_scene_broadcast
+        w, h, ns, depth = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        lib().cray_scene_info(self._h, C.byref(w), C.byref(h), C.byref(ns), C.byref(depth))
+        self.width, self.height, self.num_samples, self.max_depth = w.value, h.value, ns.value, depth.value
+        self.device_bytes = lib().cray_scene_device_bytes(self._h)
 
     def params(self, seed=0, rank=0, world_size=1, sample_range=None, count_traversal=False, max_paths_in_flight=0):
         p = RenderParams()
@@ -248,17 +353,37 @@ class DeviceScene:
         return p
 
     def render(self, seed=0, rank=0, world_size=1, sample_range=None, count_traversal=False, max_paths_in_flight=0,
-               out_device_ptr=None):
-        """Returns (film[h, w, 3] float32 or None when writing to out_device_ptr, stats dict)."""
+               out_device_ptr=None, out=None):
+        """Returns (film[h, w, 3] float32 or None when writing to out_device_ptr, stats dict); `out`: a C-contiguous
+        float32 [h, w, 3] host array to fill (e.g. pinned memory) instead of a new one."""
         p = self.params(seed, rank, world_size, sample_range, count_traversal, max_paths_in_flight)
         st = Stats()
         if out_device_ptr is not None:
             p.out_is_device = 1
             _check(lib().cray_render(self.ctx._h, self._h, C.byref(p), C.c_void_p(out_device_ptr), C.byref(st)), 'cray_render')
             return None, st.as_dict()
-        out = np.zeros((self.height, self.width, 3), dtype=np.float32)
+        if out is None:
+            out = np.zeros((self.height, self.width, 3), dtype=np.float32)
+        assert out.dtype == np.float32 and out.shape == (self.height, self.width, 3) and out.flags['C_CONTIGUOUS']
         _check(lib().cray_render(self.ctx._h, self._h, C.byref(p), out.ctypes.data, C.byref(st)), 'cray_render')
         return out, st.as_dict()
+
+    def render_gather(self, seed=0, sample_range=None, max_paths_in_flight=0, out=None, out_device_ptr=None):
+        """cray_render_gather: this rank's tiles (rank / world of the context's communicator), then the RCCL gather.
+        Rank 0 gets the film (numpy [H, W, 3], or written to out_device_ptr); other ranks get None. Returns (film, stats)."""
+        p = self.params(seed, 0, 1, sample_range, False, max_paths_in_flight)
+        st = Stats()
+        root = self.ctx.comm_rank() == 0
+        dst = None
+        if out_device_ptr is not None:
+            p.out_is_device = 1
+            dst = C.c_void_p(out_device_ptr) if root else None
+        elif root:
+            if out is None:
+                out = np.zeros((self.height, self.width, 3), dtype=np.float32)
+            dst = C.c_void_p(out.ctypes.data)
+        _check(lib().cray_render_gather(self.ctx._h, self._h, C.byref(p), dst, C.byref(st)), 'cray_render_gather')
+        return (out if root and out_device_ptr is None else None), st.as_dict()
 
     def render_samples(self, sample_range, seed=0):
         """Per-path radiance L[h, w, n, 3] (f64) of samples [a, b)."""

@@ -6,6 +6,9 @@
 // on one HIP stream without any host round trip: queue lengths live in device memory and
 // the kernels read them, so a whole frame is a fixed launch sequence.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types and prototypes only: librccl.so.1 is dlopen'ed by the first cray_comm_* call
+
+#include <dlfcn.h>
 
 #include <chrono>
 #include <cstdarg>
@@ -76,14 +79,30 @@ struct cray_ctx {
     bool pix_count_valid = false;
     float* film = nullptr;
     size_t film_floats = 0;
+    float* out_stage = nullptr;  // resolved film on the device when the caller's out_rgb is host memory (no per-frame hipMalloc)
+    size_t out_stage_floats = 0;
     // event pool for per-family kernel timing
     std::vector<hipEvent_t> events;
+    // multi-GPU (cray_comm_*): one communicator per context, Film tiles gathered to rank 0
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
+    double* comm_scratch = nullptr;      // 64 doubles on the device (barrier word, host-value all-reduces, scene header)
+    float* packed = nullptr;             // this rank's tiles, packed (ranks != 0)
+    size_t packed_floats = 0;
+    float* gathered = nullptr;           // rank 0: every rank's packed tiles, concatenated in rank order
+    size_t gathered_floats = 0;
+    uint32_t* all_pix = nullptr;         // rank 0: pixel index of every position of `gathered`
+    size_t all_pix_capacity = 0;
+    uint64_t all_key[5] = {0, 0, 0, 0, 0};  // (W, H, tile w, tile h, world) of all_pix
+    bool all_valid = false;
+    std::vector<size_t> rank_offset;     // world + 1 prefix sums of the per-rank pixel counts
 };
 
 struct cray_scene {
     cray_ctx* ctx = nullptr;
     DevScene dev{};
     std::vector<void*> allocs;
+    std::vector<size_t> alloc_bytes;  // parallel to allocs, in the order of scene_arrays()
     uint64_t bytes = 0;
     uint32_t n_prims = 0;
 };
@@ -98,6 +117,7 @@ int upload(cray_scene* s, const T* host, size_t n, const T** out) {
     void* d = nullptr;
     HIP_TRY(hipMalloc(&d, bytes));
     s->allocs.push_back(d);
+    s->alloc_bytes.push_back(bytes);
     s->bytes += bytes;
     if (n) HIP_TRY(hipMemcpy(d, host, n * sizeof(T), hipMemcpyHostToDevice));
     *out = (const T*)d;
@@ -221,6 +241,8 @@ void fill_stats(const Counters& h, cray_stats* st) {
 
 extern "C" const char* cray_last_error(void) { return g_err; }
 
+static void comm_release(cray_ctx* c);  // cray_comm section at the end of this file
+
 extern "C" int cray_ctx_create(int device_id, void* stream, cray_ctx** out) {
     if (!out) { set_last_error("cray_ctx_create: out is null"); return CRAY_ERR_INVALID; }
     *out = nullptr;
@@ -239,11 +261,19 @@ extern "C" int cray_ctx_create(int device_id, void* stream, cray_ctx** out) {
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else { HIP_TRY(hipStreamCreate(&c->stream)); c->own_stream = true; }
     HIP_TRY(hipMalloc((void**)&c->counters, sizeof(Counters)));
-    if (const char* e = getenv("CRAY_MIX_TRACE")) c->mix_trace = atoi(e);
-    if (const char* e = getenv("CRAY_REFILL_MIN")) c->refill_min = (unsigned int)atoi(e);
-    if (const char* e = getenv("CRAY_TRACE_BLOCKS_PER_CU")) c->trace_blocks_per_cu = atoi(e);
-    if (const char* e = getenv("CRAY_SHADE_BLOCKS_PER_CU")) c->shade_blocks_per_cu = atoi(e);
-    if (const char* e = getenv("CRAY_SORT_SHADE")) c->sort_shade = atoi(e);
+    // experiment knobs, clamped to the ranges the kernels are written for (refill_min > 64 would leave the persistent
+    // waves of k_trace spinning without ever fetching a ray; a grid of 0 blocks is a launch error)
+    auto env_int = [](const char* name, int lo, int hi, int dflt) {
+        const char* e = getenv(name);
+        if (!e || !*e) return dflt;
+        const int v = atoi(e);
+        return v < lo ? lo : (v > hi ? hi : v);
+    };
+    c->mix_trace = env_int("CRAY_MIX_TRACE", 0, 1, c->mix_trace);
+    c->refill_min = (unsigned int)env_int("CRAY_REFILL_MIN", 1, 64, (int)c->refill_min);
+    c->trace_blocks_per_cu = env_int("CRAY_TRACE_BLOCKS_PER_CU", 1, 16, c->trace_blocks_per_cu);
+    c->shade_blocks_per_cu = env_int("CRAY_SHADE_BLOCKS_PER_CU", 1, 64, c->shade_blocks_per_cu);
+    c->sort_shade = env_int("CRAY_SORT_SHADE", 0, 1, c->sort_shade);
     *out = c;
     return CRAY_OK;
 }
@@ -257,6 +287,8 @@ extern "C" void cray_ctx_destroy(cray_ctx* c) {
     if (c->deep_key) (void)hipFree(c->deep_key);
     if (c->pix_list) (void)hipFree(c->pix_list);
     if (c->film) (void)hipFree(c->film);
+    if (c->out_stage) (void)hipFree(c->out_stage);
+    comm_release(c);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -269,6 +301,13 @@ extern "C" void cray_scene_free(cray_scene* s) {
     delete s;
 }
 extern "C" uint64_t cray_scene_device_bytes(const cray_scene* s) { return s ? s->bytes : 0; }
+extern "C" void cray_scene_info(const cray_scene* s, uint32_t* w, uint32_t* h, uint32_t* ns, uint32_t* depth) {
+    if (!s) return;
+    if (w) *w = s->dev.film_w;
+    if (h) *h = s->dev.film_h;
+    if (ns) *ns = s->dev.num_samples;
+    if (depth) *depth = s->dev.max_depth;
+}
 
 // Flattened reference-topology BVH -> device layout (cray_device.h).
 extern "C" int cray_scene_upload(cray_ctx* c, const cray_flat_scene* f, cray_scene** out) {
@@ -373,6 +412,10 @@ extern "C" int cray_scene_upload(cray_ctx* c, const cray_flat_scene* f, cray_sce
         if (l.prim < 0 || (uint32_t)l.prim >= f->n_prims) { set_last_error("area light %u: bad primitive", i); e = CRAY_ERR_INVALID; break; }
         const cray_prim& p = f->prims[l.prim];
         o.shape_kind = p.shape_kind; o.shape = p.shape;
+        if ((p.shape_kind == CRAY_SHAPE_TRIANGLE && p.shape >= f->n_triangles) || (p.shape_kind == CRAY_SHAPE_SPHERE && p.shape >= f->n_spheres) ||
+            (p.shape_kind == CRAY_SHAPE_DISK && p.shape >= f->n_disks) || p.shape_kind < CRAY_SHAPE_SPHERE || p.shape_kind > CRAY_SHAPE_DISK) {
+            set_last_error("area light %u: bad shape", i); e = CRAY_ERR_INVALID; break;
+        }
         if (p.shape_kind == CRAY_SHAPE_TRIANGLE) {
             const cray_triangle& t = f->triangles[p.shape];
             o.v0[0] = t.v0.x; o.v0[1] = t.v0.y; o.v0[2] = t.v0.z;
@@ -392,6 +435,37 @@ extern "C" int cray_scene_upload(cray_ctx* c, const cray_flat_scene* f, cray_sce
             e = CRAY_ERR_INVALID;
         }
     }
+    // material / texture / image tables are indexed by the kernels (and below on the host): check every index once
+    for (uint32_t i = 0; i < f->n_materials && !e; i++) {
+        const cray_material& m = f->materials[i];
+        const int64_t nb = m.is_bsdf ? m.n_bxdfs : 1;
+        if (m.n_bxdfs < 0 || m.first_bxdf < 0 || (nb > 0 && (int64_t)m.first_bxdf + nb > (int64_t)f->n_bxdfs)) {
+            set_last_error("material %u: lobes [%d, %d + %lld) outside the %u bxdfs", i, m.first_bxdf, m.first_bxdf, (long long)nb, f->n_bxdfs);
+            e = CRAY_ERR_INVALID;
+        }
+    }
+    for (uint32_t i = 0; i < f->n_bxdfs && !e; i++) {
+        const cray_bxdf& bx = f->bxdfs[i];
+        if (bx.kind < CRAY_BXDF_LAMBERTIAN || bx.kind > CRAY_BXDF_FRESNEL_SPECULAR || bx.tex_a >= (int32_t)f->n_textures || bx.tex_b >= (int32_t)f->n_textures) {
+            set_last_error("bxdf %u: bad kind or texture index", i);
+            e = CRAY_ERR_INVALID;
+        }
+    }
+    for (uint32_t i = 0; i < f->n_textures && !e; i++) {
+        const cray_texture& t = f->textures[i];
+        if (t.kind < CRAY_TEX_CONSTANT || t.kind > CRAY_TEX_IMAGE || (t.kind == CRAY_TEX_IMAGE && (t.image < 0 || t.image >= (int32_t)f->n_images))) {
+            set_last_error("texture %u: bad kind or image index", i);
+            e = CRAY_ERR_INVALID;
+        }
+    }
+    for (uint32_t i = 0; i < f->n_images && !e; i++) {
+        const cray_image& im = f->images[i];
+        const uint64_t bytes = (uint64_t)im.width * im.height * 3;
+        if (im.width == 0 || im.height == 0 || im.offset > f->image_pool_bytes || bytes > f->image_pool_bytes - im.offset) {
+            set_last_error("image %u: %ux%u at offset %llu does not fit the %llu-byte pool", i, im.width, im.height, (unsigned long long)im.offset, (unsigned long long)f->image_pool_bytes);
+            e = CRAY_ERR_INVALID;
+        }
+    }
     double gamma_lut[256];  // Color::from_rgb (color.rs:39-46): (c/255).powf(2.2), libm pow like the reference
     for (int i = 0; i < 256; i++) gamma_lut[i] = pow((double)i / 255.0, 2.2);
 
@@ -406,6 +480,7 @@ extern "C" int cray_scene_upload(cray_ctx* c, const cray_flat_scene* f, cray_sce
     std::vector<cray_material> mats(f->materials, f->materials + f->n_materials);
     for (cray_material& m : mats) {
         m.pad_ = 0;
+        if (e) break;
         const int nb = m.is_bsdf ? m.n_bxdfs : 1;
         for (int i = 0; i < nb; i++) {
             const cray_bxdf& bx = f->bxdfs[m.first_bxdf + i];
@@ -571,102 +646,123 @@ std::vector<PassPlan> plan(size_t capacity, uint32_t n_pix, uint32_t s_begin, ui
 
 }  // namespace
 
-extern "C" int cray_render(cray_ctx* c, cray_scene* s, const cray_render_params* prm, float* out_rgb, cray_stats* stats) {
-    int e = check_render_args(c, s, prm);
+namespace {
+
+template <class T>
+int ensure_buffer(T** buf, size_t* have, size_t want) {
+    if (*have >= want && *buf) return CRAY_OK;
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr; *have = 0;
+    HIP_TRY(hipMalloc((void**)buf, (want ? want : 1) * sizeof(T)));
+    *have = want;
+    return CRAY_OK;
+}
+
+// The pixel list of (film, tiles, rank, world) stays on the device between frames.
+int ensure_pix_list(cray_ctx* c, uint32_t W, uint32_t H, const cray_render_params& prm) {
+    const uint64_t pix_key[6] = {W, H, prm.tile_width, prm.tile_height, prm.rank, prm.world_size};
+    if (c->pix_count_valid && memcmp(pix_key, c->pix_key, sizeof(pix_key)) == 0) return CRAY_OK;
+    std::vector<uint32_t> pix = rank_pixels(W, H, prm);
+    c->pix_count_valid = false;
+    int e = ensure_buffer(&c->pix_list, &c->pix_capacity, pix.size());
     if (e) return e;
-    if (!out_rgb) { set_last_error("cray_render: out_rgb is null"); return CRAY_ERR_INVALID; }
-    HIP_TRY(hipSetDevice(c->device));
+    if (!pix.empty()) HIP_TRY(hipMemcpyAsync(c->pix_list, pix.data(), pix.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // pix is a local vector
+    memcpy(c->pix_key, pix_key, sizeof(pix_key));
+    c->pix_count = pix.size();
+    c->pix_count_valid = true;
+    return CRAY_OK;
+}
+
+// Every pass of this rank's share of the frame, accumulated into c->film (sums over samples, not yet divided by
+// num_samples); fills everything of `stats` but `seconds`.  Local to the rank: no collective in here, so a rank that
+// has to repeat its frame with the deep traversal stack does not disturb the others.
+int render_local(cray_ctx* c, cray_scene* s, const cray_render_params* prm, cray_stats* stats) {
     const DevScene& d = s->dev;
     const uint32_t W = d.film_w, H = d.film_h;
     uint32_t s_begin = prm->sample_begin, s_end = prm->sample_end;
     if (s_begin == 0 && s_end == 0) s_end = d.num_samples;
     if (s_end > d.num_samples) s_end = d.num_samples;
-
-    // the pixel list of (film, tiles, rank, world) stays on the device between frames
-    const uint64_t pix_key[6] = {W, H, prm->tile_width, prm->tile_height, prm->rank, prm->world_size};
-    const bool pix_cached = c->pix_count_valid && memcmp(pix_key, c->pix_key, sizeof(pix_key)) == 0;
-    std::vector<uint32_t> pix;
-    if (!pix_cached) {
-        pix = rank_pixels(W, H, *prm);
-        c->pix_count_valid = false;
-        if (pix.size() > c->pix_capacity) {
-            if (c->pix_list) (void)hipFree(c->pix_list);
-            c->pix_list = nullptr; c->pix_capacity = 0;
-            HIP_TRY(hipMalloc((void**)&c->pix_list, pix.size() * 4));
-            c->pix_capacity = pix.size();
-        }
-    }
-    const size_t n_pix_rank = pix_cached ? c->pix_count : pix.size();
+    int e;
+    if ((e = ensure_pix_list(c, W, H, *prm))) return e;
+    const size_t n_pix_rank = c->pix_count;
     const size_t film_floats = (size_t)W * H * 3;
-    if (film_floats > c->film_floats) {
-        if (c->film) (void)hipFree(c->film);
-        c->film = nullptr; c->film_floats = 0;
-        HIP_TRY(hipMalloc((void**)&c->film, film_floats * sizeof(float)));
-        c->film_floats = film_floats;
-    }
+    if ((e = ensure_buffer(&c->film, &c->film_floats, film_floats))) return e;
     size_t capacity = prm->max_paths_in_flight ? (size_t)prm->max_paths_in_flight : ((size_t)32 << 20);
-    size_t need = n_pix_rank * (s_end > s_begin ? s_end - s_begin : 0);
+    const size_t need = n_pix_rank * (s_end > s_begin ? s_end - s_begin : 0);
     if (need < capacity) capacity = need;
     if (capacity < prm->sample_batch) capacity = prm->sample_batch;
     if (capacity >= ((size_t)1 << 32)) capacity = ((size_t)1 << 32) - 1;
     if ((e = ensure_state(c, capacity))) return e;
-    std::vector<PassPlan> passes = plan(c->capacity, (uint32_t)n_pix_rank, s_begin, s_end, prm->sample_batch);
+    const std::vector<PassPlan> passes = plan(c->capacity, (uint32_t)n_pix_rank, s_begin, s_end, prm->sample_batch);
 
-    if (!pix_cached) {
-        if (!pix.empty()) HIP_TRY(hipMemcpyAsync(c->pix_list, pix.data(), pix.size() * 4, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));  // pix is a local vector
-        memcpy(c->pix_key, pix_key, sizeof(pix_key));
-        c->pix_count = pix.size();
-        c->pix_count_valid = true;
-    }
-    HIP_TRY(hipMemsetAsync(c->film, 0, film_floats * sizeof(float), c->stream));
-    if ((e = reset_counters(c))) return e;
-    HIP_TRY(hipStreamSynchronize(c->stream));
-
-    EventTimer timer(c);
-    EventTimer* tm = stats ? &timer : nullptr;
-    auto t0 = std::chrono::steady_clock::now();
-    for (const PassPlan& pp : passes)
-        if ((e = run_pass(c, s, *prm, pp, tm))) return e;
-
-    float* dst = out_rgb;
-    float* staging = nullptr;
-    if (!prm->out_is_device) {
-        HIP_TRY(hipMalloc((void**)&staging, film_floats * sizeof(float)));
-        dst = staging;
-    }
-    hipLaunchKernelGGL(k_resolve, dim3(grid_for(c, film_floats, 8)), dim3(kBlock), 0, c->stream, c->film, dst, film_floats, (float)d.num_samples);
-    hipError_t err = hipStreamSynchronize(c->stream);
-    auto t1 = std::chrono::steady_clock::now();
-    if (err == hipSuccess && staging) err = hipMemcpy(out_rgb, staging, film_floats * sizeof(float), hipMemcpyDeviceToHost);
-    if (staging) (void)hipFree(staging);
-    if (err != hipSuccess) { set_last_error("render failed: %s", hipGetErrorString(err)); return CRAY_ERR_HIP; }
-
-    Counters h;
-    HIP_TRY(hipMemcpy(&h, c->counters, sizeof(h), hipMemcpyDeviceToHost));
-    if (stats) {
-        memset(stats, 0, sizeof(*stats));
-        fill_stats(h, stats);
-        stats->paths = need;
-        stats->seconds = std::chrono::duration<double>(t1 - t0).count();
-        double ms[FAM_COUNT]; uint32_t launches[FAM_COUNT];
-        if ((e = timer.collect(ms, launches))) return e;
-        stats->trace_mixed_ms = ms[FAM_MIXED]; stats->trace_mixed_launches = launches[FAM_MIXED];
-        stats->trace_closest_ms = ms[FAM_CLOSEST]; stats->trace_any_ms = ms[FAM_ANY];
-        stats->shade_ms = ms[FAM_SHADE]; stats->other_ms = ms[FAM_OTHER];
-        stats->trace_closest_launches = launches[FAM_CLOSEST]; stats->trace_any_launches = launches[FAM_ANY];
-        stats->shade_launches = launches[FAM_SHADE];
-    }
-    if (h.stack_overflow) {  // a ray needed more pending nodes than the traversal stack holds: its result is not the reference's
-        if (c->deep_depth == 0) {
+    for (int attempt = 0;; attempt++) {
+        HIP_TRY(hipMemsetAsync(c->film, 0, film_floats * sizeof(float), c->stream));
+        if ((e = reset_counters(c))) return e;
+        EventTimer timer(c);
+        EventTimer* tm = stats ? &timer : nullptr;
+        for (const PassPlan& pp : passes)
+            if ((e = run_pass(c, s, *prm, pp, tm))) return e;
+        Counters h;
+        HIP_TRY(hipMemcpyAsync(&h, c->counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        hipError_t err = hipStreamSynchronize(c->stream);
+        if (err != hipSuccess) { set_last_error("render failed: %s", hipGetErrorString(err)); return CRAY_ERR_HIP; }
+        if (stats) {
+            memset(stats, 0, sizeof(*stats));
+            fill_stats(h, stats);
+            stats->paths = need;
+            double ms[FAM_COUNT]; uint32_t launches[FAM_COUNT];
+            if ((e = timer.collect(ms, launches))) return e;
+            stats->trace_mixed_ms = ms[FAM_MIXED]; stats->trace_mixed_launches = launches[FAM_MIXED];
+            stats->trace_closest_ms = ms[FAM_CLOSEST]; stats->trace_any_ms = ms[FAM_ANY];
+            stats->shade_ms = ms[FAM_SHADE]; stats->other_ms = ms[FAM_OTHER];
+            stats->trace_closest_launches = launches[FAM_CLOSEST]; stats->trace_any_launches = launches[FAM_ANY];
+            stats->shade_launches = launches[FAM_SHADE];
+        }
+        if (!h.stack_overflow) return CRAY_OK;
+        // a ray needed more pending nodes than the traversal stack holds: its result is not the reference's
+        if (c->deep_depth == 0 && attempt == 0) {
             // first time on this context: add the third stack level (HBM) and render the frame again
             if ((e = ensure_deep(c))) return e;
-            return cray_render(c, s, prm, out_rgb, stats);
+            continue;
         }
         set_last_error("BVH deeper than the %u-entry traversal stack: %llu lane(s) overflowed; the film is not valid",
                        (unsigned)kStackDepth + c->deep_depth, h.stack_overflow);
         return CRAY_ERR_UNSUPPORTED;
     }
+}
+
+// Device destination of a finished film: the caller's device pointer, or the context's staging buffer when the caller
+// handed host memory (copied out by finish_output).
+int output_target(cray_ctx* c, const cray_render_params* prm, float* out_rgb, size_t film_floats, float** dst) {
+    if (prm->out_is_device) { *dst = out_rgb; return CRAY_OK; }
+    int e = ensure_buffer(&c->out_stage, &c->out_stage_floats, film_floats);
+    *dst = c->out_stage;
+    return e;
+}
+int finish_output(cray_ctx* c, const cray_render_params* prm, float* out_rgb, size_t film_floats) {
+    if (!prm->out_is_device && out_rgb)
+        HIP_TRY(hipMemcpyAsync(out_rgb, c->out_stage, film_floats * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    hipError_t err = hipStreamSynchronize(c->stream);
+    if (err != hipSuccess) { set_last_error("render failed: %s", hipGetErrorString(err)); return CRAY_ERR_HIP; }
+    return CRAY_OK;
+}
+
+}  // namespace
+
+extern "C" int cray_render(cray_ctx* c, cray_scene* s, const cray_render_params* prm, float* out_rgb, cray_stats* stats) {
+    int e = check_render_args(c, s, prm);
+    if (e) return e;
+    if (!out_rgb) { set_last_error("cray_render: out_rgb is null"); return CRAY_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t film_floats = (size_t)s->dev.film_w * s->dev.film_h * 3;
+    float* dst = nullptr;
+    if ((e = output_target(c, prm, out_rgb, film_floats, &dst))) return e;
+    auto t0 = std::chrono::steady_clock::now();
+    if ((e = render_local(c, s, prm, stats))) return e;
+    hipLaunchKernelGGL(k_resolve, dim3(grid_for(c, film_floats, 8)), dim3(kBlock), 0, c->stream, c->film, dst, film_floats, (float)s->dev.num_samples);
+    if ((e = finish_output(c, prm, out_rgb, film_floats))) return e;
+    if (stats) stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return CRAY_OK;
 }
 
@@ -919,5 +1015,393 @@ extern "C" int cray_bvh_build_sah(cray_ctx* c, const double* prim_bounds, uint32
         set_last_error("Bvh::new would panic in the reference (code %u: 1 zero surface area, 2 non-finite cost, 3 empty partition)", h.error);
         return CRAY_ERR_BUILD;
     }
+    return CRAY_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Multi-GPU: tile shard + gather of Film tiles over RCCL (include/cray.h "multi-GPU").
+// The reference's workers are threads adding tiles into one Mutex<Vec<f32>> (craytracer.rs:245, 271-291, 182-188);
+// here the workers are GPUs, each with the pixels of its tiles complete, and the merge is one gather to rank 0.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct Rccl {
+    void* handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+};
+static_assert(sizeof(ncclUniqueId) == CRAY_COMM_ID_BYTES, "cray_comm_id is an ncclUniqueId");
+
+// librccl.so.1: the copy already in the process (a PyTorch host has loaded its own) or the ROCm one on the library path
+Rccl* rccl() {
+    static Rccl api;
+    static bool tried = false;
+    if (api.handle) return &api;
+    if (tried) return nullptr;
+    tried = true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (api.handle) break;
+    }
+    if (!api.handle) { set_last_error("cannot load librccl.so.1: %s", dlerror()); return nullptr; }
+    bool ok = true;
+    auto sym = [&](const char* n) { void* f = dlsym(api.handle, n); if (!f) { set_last_error("librccl: missing symbol %s", n); ok = false; } return f; };
+    api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+    api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+    api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+    api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+    api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+    api.Send = (decltype(api.Send))sym("ncclSend");
+    api.Recv = (decltype(api.Recv))sym("ncclRecv");
+    api.Broadcast = (decltype(api.Broadcast))sym("ncclBroadcast");
+    api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
+    if (!ok) { dlclose(api.handle); api.handle = nullptr; return nullptr; }
+    return &api;
+}
+
+#define RCCL_TRY(R, expr)                                                                          \
+    do {                                                                                           \
+        ncclResult_t r_ = (expr);                                                                  \
+        if (r_ != ncclSuccess) {                                                                   \
+            set_last_error("%s failed: %s (%s:%d)", #expr, (R)->GetErrorString(r_), __FILE__, __LINE__); \
+            return CRAY_ERR_HIP;                                                                   \
+        }                                                                                          \
+    } while (0)
+
+// packed[3 i + k] = film[3 pix[i] + k] / div   (div = num_samples resolves the film on the way; x / 1.0f == x)
+__global__ void __launch_bounds__(kBlock) k_pack_tiles(const float* __restrict__ film, const uint32_t* __restrict__ pix, size_t n_pix, float div,
+                                                       float* __restrict__ packed) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, n = n_pix * 3;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const size_t q = i / 3;
+        packed[i] = film[(size_t)pix[q] * 3 + (i - q * 3)] / div;
+    }
+}
+// out[3 all_pix[q] + k] = gathered[3 q + k]: the rank-ordered concatenation back into the row-major film
+__global__ void __launch_bounds__(kBlock) k_unpack_tiles(const float* __restrict__ gathered, const uint32_t* __restrict__ all_pix, size_t n_pix,
+                                                         float* __restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, n = n_pix * 3;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const size_t q = i / 3;
+        out[(size_t)all_pix[q] * 3 + (i - q * 3)] = gathered[i];
+    }
+}
+
+// rank 0's map of the gathered buffer: the pixel lists of ranks 0..world-1 one after the other
+int ensure_all_pix(cray_ctx* c, uint32_t W, uint32_t H, uint32_t tw, uint32_t th, uint32_t world) {
+    const uint64_t key[5] = {W, H, tw, th, world};
+    if (c->all_valid && memcmp(key, c->all_key, sizeof(key)) == 0) return CRAY_OK;
+    c->all_valid = false;
+    std::vector<uint32_t> all;
+    all.reserve((size_t)W * H);
+    c->rank_offset.assign(world + 1, 0);
+    cray_render_params p;
+    cray_render_params_default(&p);
+    p.tile_width = tw; p.tile_height = th; p.world_size = world;
+    for (uint32_t r = 0; r < world; r++) {
+        p.rank = r;
+        const std::vector<uint32_t> mine = rank_pixels(W, H, p);
+        all.insert(all.end(), mine.begin(), mine.end());
+        c->rank_offset[r + 1] = all.size();
+    }
+    if (all.size() != (size_t)W * H) { set_last_error("internal error: tile lists cover %zu of %zu pixels", all.size(), (size_t)W * H); return CRAY_ERR_INVALID; }
+    int e = ensure_buffer(&c->all_pix, &c->all_pix_capacity, all.size());
+    if (e) return e;
+    HIP_TRY(hipMemcpyAsync(c->all_pix, all.data(), all.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(c->all_key, key, sizeof(key));
+    c->all_valid = true;
+    return CRAY_OK;
+}
+
+// Pack this rank's tiles out of `film` (dividing by `div`), move them to rank 0, and there rebuild the row-major film
+// in `dst` (device).  Collective over the ctx's communicator; c->pix_list must hold this rank's pixel list.
+int gather_tiles(cray_ctx* c, uint32_t W, uint32_t H, uint32_t tw, uint32_t th, const float* film, float div, float* dst) {
+    Rccl* R = rccl();
+    if (!R || !c->comm) { set_last_error("no communicator: call cray_comm_init first"); return CRAY_ERR_INVALID; }
+    const uint32_t world = (uint32_t)c->comm_world, rank = (uint32_t)c->comm_rank;
+    const size_t n_mine = c->pix_count;
+    int e;
+    if (rank == 0) {
+        if ((e = ensure_all_pix(c, W, H, tw, th, world))) return e;
+        if (c->rank_offset[1] != n_mine) { set_last_error("internal error: rank 0 owns %zu pixels, the map says %zu", n_mine, c->rank_offset[1]); return CRAY_ERR_INVALID; }
+        const size_t total = (size_t)W * H;
+        if ((e = ensure_buffer(&c->gathered, &c->gathered_floats, total * 3))) return e;
+        // rank 0's own tiles go straight to the head of the gathered buffer
+        if (n_mine) hipLaunchKernelGGL(k_pack_tiles, dim3(grid_for(c, n_mine * 3, 8)), dim3(kBlock), 0, c->stream, film, c->pix_list, n_mine, div, c->gathered);
+        RCCL_TRY(R, R->GroupStart());
+        for (uint32_t r = 1; r < world; r++) {
+            const size_t cnt = c->rank_offset[r + 1] - c->rank_offset[r];
+            if (cnt) RCCL_TRY(R, R->Recv(c->gathered + c->rank_offset[r] * 3, cnt * 3, ncclFloat, (int)r, c->comm, c->stream));
+        }
+        RCCL_TRY(R, R->GroupEnd());
+        hipLaunchKernelGGL(k_unpack_tiles, dim3(grid_for(c, total * 3, 8)), dim3(kBlock), 0, c->stream, (const float*)c->gathered, (const uint32_t*)c->all_pix, total, dst);
+    } else {
+        if ((e = ensure_buffer(&c->packed, &c->packed_floats, n_mine * 3))) return e;
+        if (n_mine) {
+            hipLaunchKernelGGL(k_pack_tiles, dim3(grid_for(c, n_mine * 3, 8)), dim3(kBlock), 0, c->stream, film, c->pix_list, n_mine, div, c->packed);
+            RCCL_TRY(R, R->Send(c->packed, n_mine * 3, ncclFloat, 0, c->comm, c->stream));
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return CRAY_OK;
+}
+
+// DevScene's device arrays in the order cray_scene_upload allocates them (= cray_scene::allocs)
+constexpr int kSceneArrays = 16;
+void scene_arrays(DevScene& d, const void** out[kSceneArrays]) {
+    int i = 0;
+    out[i++] = (const void**)&d.inner; out[i++] = (const void**)&d.slots; out[i++] = (const void**)&d.prims; out[i++] = (const void**)&d.tri_shade;
+    out[i++] = (const void**)&d.spheres; out[i++] = (const void**)&d.disks; out[i++] = (const void**)&d.materials; out[i++] = (const void**)&d.bxdfs;
+    out[i++] = (const void**)&d.textures; out[i++] = (const void**)&d.images; out[i++] = (const void**)&d.pool; out[i++] = (const void**)&d.gamma_lut;
+    out[i++] = (const void**)&d.lights; out[i++] = (const void**)&d.light_cdf; out[i++] = (const void**)&d.first_equal_light; out[i++] = (const void**)&d.sobol;
+}
+
+struct SceneHeader {
+    DevScene dev;  // root's copy; the pointers are replaced on the receiving side
+    uint64_t bytes[kSceneArrays];
+    uint32_t n_prims, magic;
+};
+
+}  // namespace
+
+static void comm_release(cray_ctx* c) {
+    if (c->comm) { if (Rccl* R = rccl()) (void)R->CommDestroy(c->comm); c->comm = nullptr; }
+    if (c->comm_scratch) (void)hipFree(c->comm_scratch);
+    if (c->packed) (void)hipFree(c->packed);
+    if (c->gathered) (void)hipFree(c->gathered);
+    if (c->all_pix) (void)hipFree(c->all_pix);
+    c->comm_scratch = nullptr; c->packed = nullptr; c->gathered = nullptr; c->all_pix = nullptr;
+}
+
+// A plain 16-B-per-lane streaming read of `bytes` of HBM: what the chip delivers to a kernel that only reads
+// (MI355X_MICROARCH.md: ~6.3 TB/s of the 8 TB/s spec), measured with HIP events on the ctx's stream.
+__global__ void __launch_bounds__(kBlock) k_stream_read(const double2* __restrict__ src, size_t n, double* __restrict__ sink) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double2 v = src[i];
+        acc += v.x + v.y;
+    }
+    if (acc == 123.456) *sink = acc;  // keeps the loads alive; never true for the zero-filled buffer
+}
+
+extern "C" int cray_measure_stream_read(cray_ctx* c, uint64_t bytes, int repeats, double* gb_per_s) {
+    if (!c || !gb_per_s || bytes < (1u << 20) || repeats < 1) { set_last_error("cray_measure_stream_read: bad argument"); return CRAY_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(c->device));
+    DevMem mem;
+    double2* buf;
+    double* sink;
+    const size_t n = bytes / sizeof(double2);
+    HIP_TRY(mem.get(&buf, n));
+    HIP_TRY(mem.get(&sink, 1));
+    HIP_TRY(hipMemsetAsync(buf, 0, n * sizeof(double2), c->stream));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    const dim3 grid(c->n_cu * 8);
+    hipLaunchKernelGGL(k_stream_read, grid, dim3(kBlock), 0, c->stream, (const double2*)buf, n, sink);  // warm-up
+    HIP_TRY(hipEventRecord(e0, c->stream));
+    for (int i = 0; i < repeats; i++) hipLaunchKernelGGL(k_stream_read, grid, dim3(kBlock), 0, c->stream, (const double2*)buf, n, sink);
+    HIP_TRY(hipEventRecord(e1, c->stream));
+    hipError_t err = hipStreamSynchronize(c->stream);
+    float ms = 0.f;
+    if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (err != hipSuccess) { set_last_error("cray_measure_stream_read failed: %s", hipGetErrorString(err)); return CRAY_ERR_HIP; }
+    *gb_per_s = (double)(n * sizeof(double2)) * repeats / (ms * 1e-3) / 1e9;
+    return CRAY_OK;
+}
+
+extern "C" int cray_comm_unique_id(cray_comm_id* out) {
+    if (!out) { set_last_error("cray_comm_unique_id: out is null"); return CRAY_ERR_INVALID; }
+    Rccl* R = rccl();
+    if (!R) return CRAY_ERR_UNSUPPORTED;
+    ncclUniqueId id;
+    RCCL_TRY(R, R->GetUniqueId(&id));
+    memcpy(out->bytes, &id, sizeof(id));
+    return CRAY_OK;
+}
+
+extern "C" int cray_comm_init(cray_ctx* c, const cray_comm_id* id, int rank, int world) {
+    if (!c || !id) { set_last_error("cray_comm_init: null argument"); return CRAY_ERR_INVALID; }
+    if (world < 1 || rank < 0 || rank >= world) { set_last_error("cray_comm_init: rank %d of %d", rank, world); return CRAY_ERR_INVALID; }
+    if (c->comm) { set_last_error("cray_comm_init: the context already has a communicator"); return CRAY_ERR_INVALID; }
+    Rccl* R = rccl();
+    if (!R) return CRAY_ERR_UNSUPPORTED;
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->comm_scratch) HIP_TRY(hipMalloc((void**)&c->comm_scratch, 64 * sizeof(double) > sizeof(SceneHeader) ? 64 * sizeof(double) : sizeof(SceneHeader)));
+    ncclUniqueId nid;
+    memcpy(&nid, id->bytes, sizeof(nid));
+    RCCL_TRY(R, R->CommInitRank(&c->comm, world, nid, rank));
+    c->comm_rank = rank; c->comm_world = world;
+    return CRAY_OK;
+}
+
+extern "C" int cray_comm_rank(const cray_ctx* c) { return c && c->comm ? c->comm_rank : 0; }
+extern "C" int cray_comm_world_size(const cray_ctx* c) { return c && c->comm ? c->comm_world : 1; }
+
+extern "C" int cray_comm_allreduce_f64(cray_ctx* c, double* v, int n, int op) {
+    if (!c || !v || n < 1 || n > 64 || op < 0 || op > 2) { set_last_error("cray_comm_allreduce_f64: bad argument"); return CRAY_ERR_INVALID; }
+    if (!c->comm) return CRAY_OK;  // one rank: the values are the result
+    Rccl* R = rccl();
+    if (!R) return CRAY_ERR_UNSUPPORTED;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(c->comm_scratch, v, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const ncclRedOp_t ops[3] = {ncclSum, ncclMax, ncclMin};
+    RCCL_TRY(R, R->AllReduce(c->comm_scratch, c->comm_scratch, (size_t)n, ncclDouble, ops[op], c->comm, c->stream));
+    HIP_TRY(hipMemcpyAsync(v, c->comm_scratch, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return CRAY_OK;
+}
+
+extern "C" int cray_comm_barrier(cray_ctx* c) {
+    if (!c) { set_last_error("cray_comm_barrier: ctx is null"); return CRAY_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->comm) { HIP_TRY(hipStreamSynchronize(c->stream)); return CRAY_OK; }
+    double one = 1.0;
+    return cray_comm_allreduce_f64(c, &one, 1, CRAY_REDUCE_SUM);
+}
+
+extern "C" int cray_scene_broadcast(cray_ctx* c, cray_scene* mine, int root, cray_scene** out) {
+    if (!c || !out) { set_last_error("cray_scene_broadcast: null argument"); return CRAY_ERR_INVALID; }
+    *out = nullptr;
+    const int rank = cray_comm_rank(c), world = cray_comm_world_size(c);
+    if (root < 0 || root >= world) { set_last_error("cray_scene_broadcast: root %d of %d", root, world); return CRAY_ERR_INVALID; }
+    if ((rank == root) != (mine != nullptr)) { set_last_error("cray_scene_broadcast: pass the scene on the root and NULL elsewhere"); return CRAY_ERR_INVALID; }
+    if (mine && (mine->ctx != c || mine->allocs.size() != (size_t)kSceneArrays)) { set_last_error("cray_scene_broadcast: scene does not belong to this context"); return CRAY_ERR_INVALID; }
+    if (world == 1) { *out = mine; return CRAY_OK; }
+    Rccl* R = rccl();
+    if (!R) return CRAY_ERR_UNSUPPORTED;
+    HIP_TRY(hipSetDevice(c->device));
+    SceneHeader h;
+    memset(&h, 0, sizeof(h));
+    if (mine) {
+        h.dev = mine->dev; h.n_prims = mine->n_prims; h.magic = 0x43524159u;
+        for (int i = 0; i < kSceneArrays; i++) h.bytes[i] = mine->alloc_bytes[i];
+        HIP_TRY(hipMemcpyAsync(c->comm_scratch, &h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+    }
+    RCCL_TRY(R, R->Broadcast(c->comm_scratch, c->comm_scratch, sizeof(h), ncclChar, root, c->comm, c->stream));
+    HIP_TRY(hipMemcpyAsync(&h, c->comm_scratch, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (h.magic != 0x43524159u) { set_last_error("cray_scene_broadcast: bad header from root"); return CRAY_ERR_INVALID; }
+    cray_scene* s = mine;
+    if (!mine) {
+        s = new cray_scene();
+        s->ctx = c; s->dev = h.dev; s->n_prims = h.n_prims;
+        const void** fields[kSceneArrays];
+        scene_arrays(s->dev, fields);
+        for (int i = 0; i < kSceneArrays; i++) {
+            void* d = nullptr;
+            hipError_t err = hipMalloc(&d, h.bytes[i]);
+            if (err != hipSuccess) {
+                // the other ranks are inside the collective sequence: nothing sensible can continue, but do not leak
+                set_last_error("cray_scene_broadcast: hipMalloc(%llu) failed: %s", (unsigned long long)h.bytes[i], hipGetErrorString(err));
+                cray_scene_free(s);
+                return CRAY_ERR_HIP;
+            }
+            s->allocs.push_back(d); s->alloc_bytes.push_back(h.bytes[i]); s->bytes += h.bytes[i];
+            *fields[i] = d;
+        }
+    }
+    // the big arrays (2.4 GB at 7.2 M triangles) go root HBM -> peer HBM over xGMI, one broadcast per array
+    for (int i = 0; i < kSceneArrays; i++)
+        RCCL_TRY(R, R->Broadcast(s->allocs[i], s->allocs[i], (size_t)h.bytes[i], ncclChar, root, c->comm, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *out = s;
+    return CRAY_OK;
+}
+
+extern "C" int cray_render_gather(cray_ctx* c, cray_scene* s, const cray_render_params* prm_in, float* out_rgb, cray_stats* stats) {
+    if (!c || !prm_in) { set_last_error("cray_render_gather: null argument"); return CRAY_ERR_INVALID; }
+    if (!c->comm || c->comm_world == 1) {
+        cray_render_params p1 = *prm_in;
+        p1.rank = 0; p1.world_size = 1;
+        return cray_render(c, s, &p1, out_rgb, stats);
+    }
+    cray_render_params prm = *prm_in;
+    prm.rank = (uint32_t)c->comm_rank; prm.world_size = (uint32_t)c->comm_world;
+    int e = check_render_args(c, s, &prm);
+    if (e) return e;
+    if (c->comm_rank == 0 && !out_rgb) { set_last_error("cray_render_gather: out_rgb is null on rank 0"); return CRAY_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(c->device));
+    const DevScene& d = s->dev;
+    const size_t film_floats = (size_t)d.film_w * d.film_h * 3;
+    float* dst = nullptr;
+    if (c->comm_rank == 0 && (e = output_target(c, &prm, out_rgb, film_floats, &dst))) return e;
+    auto t0 = std::chrono::steady_clock::now();
+    if ((e = render_local(c, s, &prm, stats))) return e;
+    if ((e = gather_tiles(c, d.film_w, d.film_h, prm.tile_width, prm.tile_height, c->film, (float)d.num_samples, dst))) return e;
+    if ((e = finish_output(c, &prm, c->comm_rank == 0 ? out_rgb : nullptr, film_floats))) return e;
+    if (stats) stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return CRAY_OK;
+}
+
+extern "C" int cray_film_gather(cray_ctx* c, uint32_t W, uint32_t H, uint32_t tw, uint32_t th, const float* local_film, float* out_rgb, int out_is_device) {
+    if (!c || !local_film || W == 0 || H == 0 || tw == 0 || th == 0) { set_last_error("cray_film_gather: bad argument"); return CRAY_ERR_INVALID; }
+    if (!c->comm) { set_last_error("cray_film_gather: call cray_comm_init first"); return CRAY_ERR_INVALID; }
+    if (c->comm_rank == 0 && !out_rgb) { set_last_error("cray_film_gather: out_rgb is null on rank 0"); return CRAY_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(c->device));
+    cray_render_params prm;
+    cray_render_params_default(&prm);
+    prm.tile_width = tw; prm.tile_height = th; prm.rank = (uint32_t)c->comm_rank; prm.world_size = (uint32_t)c->comm_world;
+    prm.out_is_device = out_is_device ? 1u : 0u;
+    int e;
+    if ((e = ensure_pix_list(c, W, H, prm))) return e;
+    const size_t film_floats = (size_t)W * H * 3;
+    float* dst = nullptr;
+    if (c->comm_rank == 0 && (e = output_target(c, &prm, out_rgb, film_floats, &dst))) return e;
+    if ((e = gather_tiles(c, W, H, tw, th, local_film, 1.0f, dst))) return e;
+    return finish_output(c, &prm, c->comm_rank == 0 ? out_rgb : nullptr, film_floats);
+}
+
+extern "C" int cray_film_pack(cray_ctx* c, uint32_t W, uint32_t H, uint32_t tw, uint32_t th, uint32_t rank, uint32_t world, const float* film,
+                              float* packed, uint64_t* n_pixels) {
+    if (!c || !film || !packed || !n_pixels || W == 0 || H == 0 || tw == 0 || th == 0 || world == 0 || rank >= world) { set_last_error("cray_film_pack: bad argument"); return CRAY_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(c->device));
+    cray_render_params prm;
+    cray_render_params_default(&prm);
+    prm.tile_width = tw; prm.tile_height = th; prm.rank = rank; prm.world_size = world;
+    int e;
+    if ((e = ensure_pix_list(c, W, H, prm))) return e;
+    const size_t film_floats = (size_t)W * H * 3, n_mine = c->pix_count;
+    DevMem mem;
+    float *d_film, *d_packed;
+    HIP_TRY(mem.get(&d_film, film_floats));
+    HIP_TRY(mem.get(&d_packed, n_mine * 3));
+    HIP_TRY(hipMemcpyAsync(d_film, film, film_floats * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if (n_mine) hipLaunchKernelGGL(k_pack_tiles, dim3(grid_for(c, n_mine * 3, 8)), dim3(kBlock), 0, c->stream, (const float*)d_film, (const uint32_t*)c->pix_list, n_mine, 1.0f, d_packed);
+    if (n_mine) HIP_TRY(hipMemcpyAsync(packed, d_packed, n_mine * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    *n_pixels = n_mine;
+    return CRAY_OK;
+}
+
+extern "C" int cray_film_unpack(cray_ctx* c, uint32_t W, uint32_t H, uint32_t tw, uint32_t th, uint32_t world, const float* gathered, float* out) {
+    if (!c || !gathered || !out || W == 0 || H == 0 || tw == 0 || th == 0 || world == 0) { set_last_error("cray_film_unpack: bad argument"); return CRAY_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(c->device));
+    int e;
+    if ((e = ensure_all_pix(c, W, H, tw, th, world))) return e;
+    const size_t total = (size_t)W * H;
+    DevMem mem;
+    float *d_in, *d_out;
+    HIP_TRY(mem.get(&d_in, total * 3));
+    HIP_TRY(mem.get(&d_out, total * 3));
+    HIP_TRY(hipMemcpyAsync(d_in, gathered, total * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_unpack_tiles, dim3(grid_for(c, total * 3, 8)), dim3(kBlock), 0, c->stream, (const float*)d_in, (const uint32_t*)c->all_pix, total, d_out);
+    HIP_TRY(hipMemcpyAsync(out, d_out, total * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
     return CRAY_OK;
 }

@@ -146,6 +146,8 @@ void cray_ctx_destroy(cray_ctx* ctx);
 int cray_scene_upload(cray_ctx* ctx, const cray_flat_scene* scene, cray_scene** out);
 void cray_scene_free(cray_scene* scene);
 uint64_t cray_scene_device_bytes(const cray_scene* scene);
+/* Film size, Scene.num_samples and Scene.max_depth of an uploaded (or broadcast-received) scene; any pointer may be NULL. */
+void cray_scene_info(const cray_scene* scene, uint32_t* film_width, uint32_t* film_height, uint32_t* num_samples, uint32_t* max_depth);
 
 /* Replaces `render` (craytracer.rs:224): fills out_rgb[W*H*3]. */
 int cray_render(cray_ctx* ctx, cray_scene* scene, const cray_render_params* params, float* out_rgb,
@@ -174,6 +176,67 @@ typedef struct {
 } cray_bvh_build_stats;
 int cray_bvh_build_sah(cray_ctx* ctx, const double* prim_bounds, uint32_t n, cray_bvh_node* out_nodes, uint32_t node_capacity,
                        uint32_t* out_n_nodes, uint32_t* out_prim_refs, cray_bvh_build_stats* stats);
+
+/* ---- multi-GPU: pixel-tile shard + gather of Film tiles over RCCL / xGMI -----------------------------
+ * Replaces the reference's merge point, the shared `Mutex<Vec<f32>>` every worker thread adds its tile into
+ * (src/bin/craytracer.rs:245, workers :271-291, merge :182-188), for workers that are GPUs of one node:
+ * one process (or host thread) per GPU, one cray_ctx each.  Rank r renders the 64x64 tiles with
+ * tile_index % world == r (tiles numbered like generate_tiles, :22-43) for ALL samples, so every pixel is
+ * accumulated on one GPU in the single-GPU order and the assembled film is bit-identical to a 1-GPU render.
+ * The only exchange is ONE gather of packed tiles to rank 0 after rendering (grouped ncclSend / ncclRecv:
+ * W*H*12/world bytes per rank over the direct xGMI link to rank 0); nothing is communicated while rendering.
+ *
+ *   rank 0:  cray_comm_unique_id(&id);  -> ship the 128 bytes to the other ranks (pipe, file, MPI, a TCP store)
+ *   all:     cray_ctx_create(local_gpu, NULL, &ctx); cray_comm_init(ctx, &id, rank, world);
+ *   rank 0:  parse + Scene::new + cray_scene_upload;  all: cray_scene_broadcast(ctx, scene_or_NULL, 0, &scene)
+ *            (or every rank uploads the scene itself)
+ *   all:     cray_render_gather(ctx, scene, &params, rank == 0 ? film : NULL, &stats);
+ *
+ * librccl.so.1 is loaded on the first cray_comm_* call (dlopen), so single-GPU hosts do not need it. */
+#define CRAY_COMM_ID_BYTES 128
+typedef struct { char bytes[CRAY_COMM_ID_BYTES]; } cray_comm_id;   /* = ncclUniqueId */
+
+/* ncclGetUniqueId: call on one rank, hand the bytes to all ranks by any host channel. */
+int cray_comm_unique_id(cray_comm_id* out);
+/* ncclCommInitRank on the ctx's GPU (collective: every rank calls it with the same id and world_size). */
+int cray_comm_init(cray_ctx* ctx, const cray_comm_id* id, int rank, int world_size);
+int cray_comm_rank(const cray_ctx* ctx);        /* 0 without a communicator */
+int cray_comm_world_size(const cray_ctx* ctx);  /* 1 without a communicator */
+/* All ranks wait for each other (one-word all-reduce on the ctx's stream + stream sync). */
+int cray_comm_barrier(cray_ctx* ctx);
+enum { CRAY_REDUCE_SUM = 0, CRAY_REDUCE_MAX = 1, CRAY_REDUCE_MIN = 2 };
+/* In-place all-reduce of n host doubles (timings, ray counts): every rank gets the result. n <= 64. */
+int cray_comm_allreduce_f64(cray_ctx* ctx, double* values, int n, int op);
+
+/* C1: replicate a scene that is resident on `root`'s GPU into every other rank's HBM with ncclBroadcast over xGMI
+ * (instead of parsing / building / uploading it once per rank).  On `root` pass the uploaded scene, *out == scene;
+ * elsewhere pass NULL and receive a new scene (free it with cray_scene_free). Collective. */
+int cray_scene_broadcast(cray_ctx* ctx, cray_scene* scene_on_root, int root, cray_scene** out);
+
+/* cray_render of this rank's tiles followed by the gather: params->rank / world_size are taken from the
+ * communicator.  out_rgb (W*H*3, host or device per params->out_is_device) is written on rank 0 only and may be
+ * NULL elsewhere.  stats (optional) are this rank's; stats->seconds includes the gather.  Collective.
+ * Without a communicator (or world_size 1) this is cray_render. */
+int cray_render_gather(cray_ctx* ctx, cray_scene* scene, const cray_render_params* params, float* out_rgb,
+                       cray_stats* stats);
+
+/* The gather alone, for a host that rendered with cray_render(out_is_device = 1, rank, world_size): local_film is the
+ * W*H*3 device film of this rank (pixels of other ranks' tiles are ignored). Collective. */
+int cray_film_gather(cray_ctx* ctx, uint32_t width, uint32_t height, uint32_t tile_width, uint32_t tile_height,
+                     const float* local_film_device, float* out_rgb, int out_is_device);
+
+/* The two halves of the gather on ONE GPU, for tests and for hosts with their own transport:
+ * pack: the pixels of `rank`'s tiles, tile by tile (row-major inside a tile), 3 floats each -> packed (host);
+ *       *n_pixels = how many.  film and packed are host arrays.
+ * unpack: `gathered` = the world_size packed arrays concatenated in rank order (W*H*3 floats) -> out (W*H*3). */
+int cray_film_pack(cray_ctx* ctx, uint32_t width, uint32_t height, uint32_t tile_width, uint32_t tile_height,
+                   uint32_t rank, uint32_t world_size, const float* film, float* packed, uint64_t* n_pixels);
+int cray_film_unpack(cray_ctx* ctx, uint32_t width, uint32_t height, uint32_t tile_width, uint32_t tile_height,
+                     uint32_t world_size, const float* gathered, float* out);
+
+/* Measurement aid for bench.py: GB/s of a plain 16-B-per-lane streaming read of `bytes` of HBM on this GPU (HIP events,
+ * `repeats` launches after one warm-up) — the denominator "what a read-only kernel gets on this very box". */
+int cray_measure_stream_read(cray_ctx* ctx, uint64_t bytes, int repeats, double* gb_per_s);
 
 const char* cray_last_error(void);
 

@@ -1,0 +1,112 @@
+"""The multi-GPU seam of the C ABI (include/cray.h "multi-GPU") as far as ONE GPU can exercise it.
+
+The reference merges worker tiles into one `Mutex<Vec<f32>>` (src/bin/craytracer.rs:245, 271-291, 182-188); the
+replacement is pack -> RCCL gather -> unpack.  Here:
+  * pack / unpack through the ABI against craytracer_amd.dist.rank_pixels for ragged films and world in {1, 2, 3, 8};
+  * a world-size-1 communicator (ncclCommInitRank with one rank): barrier, all-reduce, scene broadcast and
+    cray_render_gather run through librccl and give the cray_render film;
+  * the share films of cray_render(rank, world) packed per rank, concatenated and unpacked equal the unsharded film.
+The N > 1 transport itself (grouped ncclSend / ncclRecv) needs N GPUs: bench.py --gpus N and examples/multi_gpu.c.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from craytracer_amd import backend, dist, scenes
+from oracle import oracle_lib as ol
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    c = backend.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize('w,h,tile', [(200, 150, (64, 64)), (64, 64, (64, 64)), (65, 1, (64, 64)), (130, 67, (32, 16)), (300, 200, (64, 64))])
+@pytest.mark.parametrize('world', [1, 2, 3, 8])
+def test_pack_and_unpack_follow_rank_pixels(ctx, w, h, tile, world):
+    rng = np.random.default_rng(w * 1000 + h + world)
+    film = rng.standard_normal((h, w, 3)).astype(np.float32)
+    parts = []
+    for r in range(world):
+        packed = ctx.film_pack(film, r, world, tile)
+        mine = dist.rank_pixels(w, h, r, world, tile[0], tile[1])
+        assert len(packed) == len(mine)
+        assert np.array_equal(packed, film.reshape(-1, 3)[mine])      # tile by tile, row-major inside a tile
+        parts.append(packed)
+    gathered = np.concatenate(parts) if parts else np.zeros((0, 3), np.float32)
+    assert len(gathered) == w * h                                      # the shares partition the film
+    assert np.array_equal(ctx.film_unpack(gathered, w, h, world, tile), film)
+
+
+def test_world1_communicator_runs_through_rccl():
+    c = backend.Context(0)
+    assert c.comm_rank() == 0 and c.comm_world_size() == 1
+    c.comm_init(backend.Context.comm_unique_id(), 0, 1)
+    assert c.comm_rank() == 0 and c.comm_world_size() == 1
+    c.barrier()
+    assert np.array_equal(c.allreduce([1.5, -2.0, 7.0], 'sum'), [1.5, -2.0, 7.0])
+    assert np.array_equal(c.allreduce([3.0], 'max'), [3.0])
+    sc = scenes.cornell(96, 80, 8, 6)
+    dev = c.upload(backend.HostScene(sc))
+    same = c.broadcast_scene(dev, root=0)
+    assert same is dev
+    a, _ = dev.render(seed=3)
+    b, st = dev.render_gather(seed=3)
+    assert np.array_equal(a, b) and st['paths'] == 96 * 80 * 8
+    with pytest.raises(backend.CrayError):
+        c.comm_init(backend.Context.comm_unique_id(), 0, 1)           # one communicator per context
+    dev.close()
+    c.close()
+
+
+@pytest.mark.parametrize('world', [2, 3, 8])
+def test_rank_shares_packed_and_unpacked_equal_the_unsharded_film(ctx, world):
+    sc = scenes.dragon(200, 150, 8, 6, nu=60, nv=150)                  # 4 x 3 tiles, ragged right and bottom edge
+    dev = ctx.upload(backend.HostScene(sc))
+    whole, _ = dev.render(seed=1)
+    parts = []
+    for r in range(world):
+        share, _ = dev.render(seed=1, rank=r, world_size=world)        # what rank r's GPU holds before the gather
+        parts.append(ctx.film_pack(share, r, world))
+    film = ctx.film_unpack(np.concatenate(parts), 200, 150, world)
+    assert np.array_equal(film, whole)
+    o, _ = ol.OracleScene(sc).render(seed=1)
+    assert np.array_equal(film, o)
+    dev.close()
+
+
+def test_render_to_host_memory_needs_no_allocation_per_frame(ctx):
+    """cray_render with out_is_device = 0 stages through a buffer the context keeps (it used to hipMalloc / hipFree the
+    whole film on every call): the film is the same and repeated frames are identical."""
+    sc = scenes.simple(128, 96, 8, 4)
+    dev = ctx.upload(backend.HostScene(sc))
+    a, _ = dev.render(seed=0)
+    b, _ = dev.render(seed=0)
+    o, _ = ol.OracleScene(sc).render(seed=0)
+    assert np.array_equal(a, b) and np.array_equal(a, o)
+    dev.close()
+
+
+def test_c_host_multi_gpu_example_with_one_rank(tmp_path):
+    """examples/multi_gpu.c (plain C: fork one process per GPU, id over a pipe, scene broadcast, render + gather)
+    with one rank on the one GPU of this box writes the film examples/minimal.c writes."""
+    backend.lib()
+    csrc = os.path.join(ROOT, 'craytracer_amd', 'csrc')
+    exes = {}
+    for name in ('minimal', 'multi_gpu'):
+        exes[name] = str(tmp_path / name)
+        subprocess.check_call(['gcc', '-std=c11', '-Wall', '-Werror', '-I' + os.path.join(ROOT, 'include'), os.path.join(ROOT, 'examples', name + '.c'),
+                               '-L' + csrc, '-lcray_hip', '-Wl,-rpath,' + csrc, '-lm', '-o', exes[name]])
+    out1, out2 = str(tmp_path / 'a.exr'), str(tmp_path / 'b.exr')
+    r = subprocess.run([exes['minimal'], out1], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exes['multi_gpu'], '1', out2], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert np.array_equal(backend.read_exr(out1), backend.read_exr(out2))
