@@ -117,7 +117,7 @@ struct Counters {
     unsigned long long closest_rays, shadow_rays;
     unsigned long long closest_nodes, closest_prims, shadow_nodes, shadow_prims;
     unsigned long long closest_tri, shadow_tri;
-    unsigned long long nonfinite, stack_overflow, shadow_skipped;
+    unsigned long long nonfinite, stack_overflow, shadow_skipped, closest_hits;
     unsigned int n_active[2], n_shadow, trace_head;
     unsigned int n_class[kShadeClasses];
     unsigned long long diag[16];  // k_trace lane-occupancy diagnostics (CRAY_TRACE_DIAG builds only)

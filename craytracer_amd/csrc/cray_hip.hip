@@ -105,6 +105,8 @@ struct cray_scene {
     std::vector<size_t> alloc_bytes;  // parallel to allocs, in the order of scene_arrays()
     uint64_t bytes = 0;
     uint32_t n_prims = 0;
+    uint32_t features = SF_ALL;  // what the scene can make k_shade do (cray_shading.h)
+    int shade_variant = kNumShadeVariants - 1;
 };
 
 namespace {
@@ -225,7 +227,7 @@ void fill_stats(const Counters& h, cray_stats* st) {
     st->closest_nodes = h.closest_nodes; st->closest_prims = h.closest_prims;
     st->shadow_nodes = h.shadow_nodes; st->shadow_prims = h.shadow_prims;
     st->closest_tri_tests = h.closest_tri; st->shadow_tri_tests = h.shadow_tri;
-    st->nonfinite = h.nonfinite; st->stack_overflow = h.stack_overflow;
+    st->nonfinite = h.nonfinite; st->stack_overflow = h.stack_overflow; st->closest_hits = h.closest_hits;
 #ifdef CRAY_TRACE_DIAG
     for (int a = 0; a < 2; a++) {
         const unsigned long long* g = h.diag + 8 * a;
@@ -307,6 +309,14 @@ extern "C" void cray_scene_info(const cray_scene* s, uint32_t* w, uint32_t* h, u
     if (h) *h = s->dev.film_h;
     if (ns) *ns = s->dev.num_samples;
     if (depth) *depth = s->dev.max_depth;
+}
+
+// the leanest instantiation of k_shade that covers `features`
+static int pick_shade_variant(uint32_t features) {
+    int best = kNumShadeVariants - 1;
+    for (int i = 0; i < kNumShadeVariants; i++)
+        if ((kShadeVariants[i] & features) == features && __builtin_popcount(kShadeVariants[i]) < __builtin_popcount(kShadeVariants[best])) best = i;
+    return best;
 }
 
 // Flattened reference-topology BVH -> device layout (cray_device.h).
@@ -499,6 +509,37 @@ extern "C" int cray_scene_upload(cray_ctx* c, const cray_flat_scene* f, cray_sce
     if (!e) e = upload(s, f->first_equal_light, (size_t)f->n_lights, &d.first_equal_light);
     if (!e) e = upload(s, &CRAY_SOBOL_REV_VECTORS[0][0][0], (size_t)CRAY_SOBOL_SETS * CRAY_SOBOL_BITS * 4, &d.sobol);
     if (e) { cray_scene_free(s); return e; }
+    // what this scene can make k_shade do -> the leanest instantiation that covers it
+    uint32_t feat = 0;
+    for (uint32_t i = 0; i < f->n_textures; i++)
+        feat |= f->textures[i].kind == CRAY_TEX_CHECKERBOARD ? SF_TEX_CHECKER : (f->textures[i].kind == CRAY_TEX_IMAGE ? SF_TEX_IMAGE : 0u);
+    for (uint32_t i = 0; i < f->n_bxdfs; i++) {
+        static const uint32_t lobe_bit[6] = {0u, SF_OREN_NAYAR, SF_CONDUCTOR, SF_SPEC_BRDF, SF_SPEC_BTDF, SF_FRESNEL_SPEC};
+        feat |= lobe_bit[f->bxdfs[i].kind];
+    }
+    for (uint32_t i = 0; i < f->n_materials; i++)
+        if (f->materials[i].is_bsdf && f->materials[i].n_bxdfs != 1) feat |= SF_MULTI_LOBE;
+    for (uint32_t i = 0; i < f->n_lights; i++) {
+        const int k = f->lights[i].kind;
+        if (k == CRAY_LIGHT_POINT) feat |= SF_LIGHT_POINT;
+        else if (k == CRAY_LIGHT_DISTANT) feat |= SF_LIGHT_DISTANT;
+        else if (k == CRAY_LIGHT_INFINITE) feat |= SF_LIGHT_INFINITE;
+        else {
+            const int sk = f->prims[f->lights[i].prim].shape_kind;
+            feat |= sk == CRAY_SHAPE_TRIANGLE ? SF_AREA_TRI : (sk == CRAY_SHAPE_SPHERE ? SF_AREA_SPHERE : SF_AREA_DISK);
+        }
+    }
+    if (f->n_lights > 1) feat |= SF_MANY_LIGHTS;
+    for (uint32_t i = 0; i < f->n_prims; i++) {
+        const int sk = f->prims[i].shape_kind;
+        feat |= sk == CRAY_SHAPE_TRIANGLE ? SF_HIT_TRI : (sk == CRAY_SHAPE_SPHERE ? SF_HIT_SPHERE : SF_HIT_DISK);
+    }
+    s->features = feat;
+    s->shade_variant = pick_shade_variant(feat);
+    if (const char* ev = getenv("CRAY_SHADE_VARIANT")) {  // experiments: force an instantiation that still covers the scene
+        const int v = atoi(ev);
+        if (v >= 0 && v < kNumShadeVariants && (kShadeVariants[v] & feat) == feat) s->shade_variant = v;
+    }
     *out = s;
     return CRAY_OK;
 }
@@ -527,6 +568,20 @@ std::vector<uint32_t> rank_pixels(uint32_t W, uint32_t H, const cray_render_para
     }
     return pix;
 }
+
+template <int I>
+struct ShadeLaunch {
+    template <class... A>
+    static void go(int variant, dim3 grid, hipStream_t st, A... args) {
+        if (variant == I) hipLaunchKernelGGL((k_shade<kShadeVariants[I]>), grid, dim3(kBlock), 0, st, args...);
+        else ShadeLaunch<I + 1>::go(variant, grid, st, args...);
+    }
+};
+template <>
+struct ShadeLaunch<kNumShadeVariants> {
+    template <class... A>
+    static void go(int, dim3, hipStream_t, A...) {}
+};
 
 int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const PassPlan& pp, EventTimer* tm) {
     const DevScene& d = s->dev;
@@ -570,10 +625,10 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
         if (c->sort_shade) {
             hipLaunchKernelGGL(k_classify, dim3(grid_for(c, n_paths, 8)), dim3(kBlock), 0, st, d, c->ps, q, nq, n_paths, c->class_queues, c->capacity, ctr->n_class);
             for (int cl = 0; cl < kShadeClasses; cl++)
-                hipLaunchKernelGGL(k_shade, dim3(g_shade), dim3(kBlock), 0, st, d, c->ps, (const uint32_t*)(c->class_queues + (size_t)cl * c->capacity),
+                ShadeLaunch<0>::go(s->shade_variant, dim3(g_shade), st, d, c->ps, (const uint32_t*)(c->class_queues + (size_t)cl * c->capacity),
                                    (const unsigned int*)&ctr->n_class[cl], 0u, b, spp_pass, pp.s_lo, q_next, n_next, c->shadow_queue, &ctr->n_shadow, ctr, trace_all);
         } else {
-            hipLaunchKernelGGL(k_shade, dim3(g_shade), dim3(kBlock), 0, st, d, c->ps, q, nq, n_paths, b, spp_pass, pp.s_lo, q_next, n_next,
+            ShadeLaunch<0>::go(s->shade_variant, dim3(g_shade), st, d, c->ps, q, nq, n_paths, b, spp_pass, pp.s_lo, q_next, n_next,
                                c->shadow_queue, &ctr->n_shadow, ctr, trace_all);
         }
         if (tm) { int e = tm->end(); if (e) return e; }
@@ -1169,7 +1224,8 @@ void scene_arrays(DevScene& d, const void** out[kSceneArrays]) {
 struct SceneHeader {
     DevScene dev;  // root's copy; the pointers are replaced on the receiving side
     uint64_t bytes[kSceneArrays];
-    uint32_t n_prims, magic;
+    uint32_t n_prims, magic, features;
+    int32_t shade_variant;
 };
 
 }  // namespace
@@ -1288,6 +1344,7 @@ extern "C" int cray_scene_broadcast(cray_ctx* c, cray_scene* mine, int root, cra
     memset(&h, 0, sizeof(h));
     if (mine) {
         h.dev = mine->dev; h.n_prims = mine->n_prims; h.magic = 0x43524159u;
+        h.features = mine->features; h.shade_variant = mine->shade_variant;
         for (int i = 0; i < kSceneArrays; i++) h.bytes[i] = mine->alloc_bytes[i];
         HIP_TRY(hipMemcpyAsync(c->comm_scratch, &h, sizeof(h), hipMemcpyHostToDevice, c->stream));
     }
@@ -1299,6 +1356,7 @@ extern "C" int cray_scene_broadcast(cray_ctx* c, cray_scene* mine, int root, cra
     if (!mine) {
         s = new cray_scene();
         s->ctx = c; s->dev = h.dev; s->n_prims = h.n_prims;
+        s->features = h.features; s->shade_variant = h.shade_variant;
         const void** fields[kSceneArrays];
         scene_arrays(s->dev, fields);
         for (int i = 0; i < kSceneArrays; i++) {

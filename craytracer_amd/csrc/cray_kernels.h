@@ -383,6 +383,7 @@ __global__ void __launch_bounds__(kBlock) k_classify(DevScene sc, PathState ps, 
 #ifndef CRAY_SHADE_WAVES
 #define CRAY_SHADE_WAVES 2
 #endif
+template <uint32_t F>
 __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
                                                   const unsigned int* __restrict__ n_ptr, uint32_t n_fixed, uint32_t bounce,
                                                   uint32_t spp_pass, uint32_t s_lo, uint32_t* __restrict__ next_queue,
@@ -394,14 +395,14 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
     // tile.  One atomic per wave on a single device-wide counter (~88 returning atomics/us per word,
     // MI355X_MICROARCH.md "dequeue") was half of this kernel's time: 1 M atomics per 33 M-path launch.
     __shared__ uint32_t l_shadow[kShadeTile], l_next[kShadeTile];
-    __shared__ unsigned int c_shadow, c_next, c_skip, g_shadow, g_next;
+    __shared__ unsigned int c_shadow, c_next, c_skip, c_hit, g_shadow, g_next;
     const uint32_t n_tiles = (n + kShadeTile - 1) / kShadeTile;
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-      if (threadIdx.x == 0) { c_shadow = 0; c_next = 0; c_skip = 0; }
+      if (threadIdx.x == 0) { c_shadow = 0; c_next = 0; c_skip = 0; c_hit = 0; }
       __syncthreads();
       for (uint32_t k = 0; k < kShadeTile / kBlock; k++) {
         const uint32_t i = tile * kShadeTile + k * kBlock + threadIdx.x;
-        bool want_shadow = false, want_next = false, skip_shadow = false;
+        bool want_shadow = false, want_next = false, skip_shadow = false, was_hit = false;
         uint32_t p = 0;
         if (i < n) {
             p = queue ? queue[i] : i;
@@ -423,7 +424,7 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
             if (hp < 0) {
                 // escaped: Light::Le is non-black only for Infinite lights (light.rs:161-168)
                 bool state_loaded = false;
-                for (uint32_t li = 0; li < sc.n_lights; li++) {
+                for (uint32_t li = 0; CRAY_HAS(F, SF_LIGHT_INFINITE) && li < sc.n_lights; li++) {
                     const DevLight& l = sc.lights[li];
                     if (l.kind != CRAY_LIGHT_INFINITE) continue;
                     if (!state_loaded) {
@@ -443,12 +444,14 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
                 }
                 if (L_loaded) { ps.lr[p] = L.r; ps.lg[p] = L.g; ps.lb[p] = L.b; }
             } else {
+                was_hit = true;
                 const ray_t ray = mkray(mk(ps.ox[p], ps.oy[p], ps.oz[p]), mk(ps.dx[p], ps.dy[p], ps.dz[p]));
                 const vec3 w_o = flip(ray.d);
                 beta = bounce == 0 ? mkc(1, 1, 1) : mkc(ps.br[p], ps.bg[p], ps.bb[p]);  // camera rays: beta = WHITE
                 const cray_prim pr = sc.prims[hp];
                 const int32_t mat = pr.light >= 0 ? -1 : pr.material;
-                const SurfPoint sp = surface_at(sc, pr, ray, ps.ht[p], ps.hu[p], ps.hv[p], mat >= 0 && sc.materials[mat].pad_ != 0);
+                const bool need_uv = CRAY_HAS(F, SF_TEX_CHECKER | SF_TEX_IMAGE) && mat >= 0 && sc.materials[mat].pad_ != 0;
+                const SurfPoint sp = surface_at<F>(sc, pr, ray, ps.ht[p], ps.hu[p], ps.hv[p], need_uv);
                 const vec3 n_s = sp.normal, x = sp.location;
 
                 // PathSegmentSamples::from (path_integrator.rs:26-36): dims 4+8k .. 11+8k
@@ -467,7 +470,7 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
                         if (specular_bounce) {
                             add_L(beta * Le);
                         } else {
-                            double lp = light_shape_pdf_from(sc, l, x, n_s, w_o);
+                            double lp = light_shape_pdf_from<F>(sc, l, x, n_s, w_o);
                             double light_pdf = lp * light_select_pdf(sc, (uint32_t)sc.first_equal_light[pr.light]);
                             prev_pdf = ps.prev_pdf[p];  // bounce > 0 here
                             double w = power_heuristic(light_pdf, prev_pdf);
@@ -485,13 +488,14 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
                     skip_shadow = true;
                 } else {
                     double sel_pdf;
-                    const uint32_t li = light_select(sc, sa[3], sel_pdf);
+                    const uint32_t li = light_select<F>(sc, sa[3], sel_pdf);
                     const DevLight& l = sc.lights[li];
-                    vec3 w_i;
+                    vec3 w_i = mk(0, 0, 1);
                     rgb Li = mkc(l.c[0], l.c[1], l.c[2]);
                     double lpdf = 0.0, s_tmax = inf64();
                     bool delta = false;
-                    if (l.kind == CRAY_LIGHT_POINT) {  // light.rs:65-79
+                    constexpr uint32_t kArea = SF_AREA_TRI | SF_AREA_SPHERE | SF_AREA_DISK;
+                    if (CRAY_HAS(F, SF_LIGHT_POINT) && (!CRAY_HAS(F, SF_LIGHT_DISTANT | SF_LIGHT_INFINITE | kArea) || l.kind == CRAY_LIGHT_POINT)) {  // light.rs:65-79
                         vec3 op = mk(l.v[0], l.v[1], l.v[2]) - x;
                         double d2 = len2(op);
                         double dist = sqrt(d2);
@@ -499,30 +503,30 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
                         if (dist > kEps) s_tmax = dist;  // update_max_distance on a fresh ray
                         Li = Li / d2;
                         delta = true;
-                    } else if (l.kind == CRAY_LIGHT_DISTANT) {  // :80-96
+                    } else if (CRAY_HAS(F, SF_LIGHT_DISTANT) && (!CRAY_HAS(F, SF_LIGHT_INFINITE | kArea) || l.kind == CRAY_LIGHT_DISTANT)) {  // :80-96
                         w_i = mk(l.v[0], l.v[1], l.v[2]);
                         delta = true;
-                    } else if (l.kind == CRAY_LIGHT_INFINITE) {  // :97-113
+                    } else if (CRAY_HAS(F, SF_LIGHT_INFINITE) && (!CRAY_HAS(F, kArea) || l.kind == CRAY_LIGHT_INFINITE)) {  // :97-113
                         vec3 nn = sb[0] < 0.5 ? mk(1, 0, 0) : mk(-1, 0, 0);
                         vec3 r = sample_sphere(sb[1], sb[2]);
                         w_i = dot(r, nn) > 0.0 ? r : flip(r);  // sample_hemisphere
                         lpdf = kInvPi / 4.0;
-                    } else {  // Area, :114-131 + Shape::sample_from (shape.rs:472-484)
-                        vec3 pt = light_shape_sample(sc, l, sb[1], sb[2]);
+                    } else if (CRAY_HAS(F, kArea)) {  // Area, :114-131 + Shape::sample_from (shape.rs:472-484)
+                        vec3 pt = light_shape_sample<F>(sc, l, sb[1], sb[2]);
                         w_i = unit(pt - x);
-                        lpdf = light_shape_pdf_from(sc, l, x, n_s, w_i);
+                        lpdf = light_shape_pdf_from<F>(sc, l, x, n_s, w_i);
                         double dist = len(pt - x);
                         double tm = dist - kEps;
                         if (tm > kEps) s_tmax = tm;
                     }
-                    rgb f = material_f(sc, mat, w_o, w_i, n_s, sp.u, sp.v);
+                    rgb f = material_f<F>(sc, mat, w_o, w_i, n_s, sp.u, sp.v);
                     double cos_t = fabs(dot(w_i, n_s));
                     rgb contrib = mkc(0, 0, 0);
                     if (!delta) {
                         if (lpdf > 0.0) {
                             double light_pdf = lpdf * sel_pdf;
                             double bsdf_pdf = 0.0;
-                            if (!material_pdf(sc, mat, w_o, w_i, n_s, bsdf_pdf)) bsdf_pdf = 0.0;
+                            if (!material_pdf<F>(sc, mat, w_o, w_i, n_s, bsdf_pdf)) bsdf_pdf = 0.0;
                             double w = power_heuristic(light_pdf, bsdf_pdf);
                             contrib = beta * Li * f * cos_t * w / light_pdf;
                         }
@@ -551,7 +555,7 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
 #else
                 // an area light's own surface is a black Lambertian (primitive.rs:40-46): its sampled f is BLACK, the
                 // path ends (`if f.is_black() { break }`, path_integrator.rs:176-178) whatever direction was drawn
-                bool go = mat >= 0 && material_sample(sc, mat, sa[0], sa[1], sa[2], w_o, n_s, sp.u, sp.v, ls);
+                bool go = mat >= 0 && material_sample<F>(sc, mat, sa[0], sa[1], sa[2], w_o, n_s, sp.u, sp.v, ls);
 #endif
                 if (go && black(ls.f)) go = false;
                 double bsdf_pdf = 0.0;
@@ -592,6 +596,8 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
         {
             const unsigned long long sk = __ballot(skip_shadow);
             if (sk != 0 && __lane_id() == (unsigned int)(__ffsll((long long)sk) - 1)) atomicAdd(&c_skip, (unsigned int)__popcll(sk));
+            const unsigned long long hk = __ballot(was_hit);
+            if (hk != 0 && __lane_id() == (unsigned int)(__ffsll((long long)hk) - 1)) atomicAdd(&c_hit, (unsigned int)__popcll(hk));
         }
       }
       __syncthreads();
@@ -599,6 +605,7 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
           g_shadow = c_shadow ? atomicAdd(shadow_count, c_shadow) : 0u;
           g_next = c_next ? atomicAdd(next_count, c_next) : 0u;
           if (c_skip) atomicAdd(&ctr->shadow_skipped, (unsigned long long)c_skip);
+          if (c_hit) atomicAdd(&ctr->closest_hits, (unsigned long long)c_hit);
       }
       __syncthreads();
       for (uint32_t j = threadIdx.x; j < c_shadow; j += kBlock) shadow_queue[g_shadow + j] = l_shadow[j];
@@ -606,6 +613,28 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
       __syncthreads();
     }
 }
+
+// The instantiations of k_shade: cray_scene_upload computes the scene's feature mask (cray_shading.h) and the launch
+// uses the variant with the fewest features among those that cover it; the last one covers everything.
+constexpr uint32_t kHitAny = SF_HIT_TRI | SF_HIT_SPHERE | SF_HIT_DISK;
+constexpr uint32_t kAreaAny = SF_AREA_TRI | SF_AREA_SPHERE | SF_AREA_DISK;
+#ifdef CRAY_VARIANTS_OVERRIDE   // compile-time experiments: hipcc -DCRAY_VARIANTS_OVERRIDE=mask,mask,...
+constexpr uint32_t kShadeVariants[] = {CRAY_VARIANTS_OVERRIDE, SF_ALL};
+#else
+constexpr uint32_t kShadeVariants[] = {
+    // constant-textured matte surfaces under area lights (Cornell-box class)
+    kHitAny | kAreaAny | SF_MANY_LIGHTS,
+    // + conductors, one disk light (dragon.cry: metal mesh on a matte ground)
+    kHitAny | SF_CONDUCTOR | SF_AREA_DISK,
+    // constant-textured plastics / metals / matte under any number of area lights
+    kHitAny | SF_OREN_NAYAR | SF_CONDUCTOR | SF_SPEC_BRDF | SF_MULTI_LOBE | kAreaAny | SF_MANY_LIGHTS,
+    // every lobe and texture kind under point + area lights (staircase.cry class: OBJ/MTL interiors)
+    kHitAny | SF_TEX_CHECKER | SF_TEX_IMAGE | SF_OREN_NAYAR | SF_CONDUCTOR | SF_SPEC_BRDF | SF_SPEC_BTDF | SF_FRESNEL_SPEC | SF_MULTI_LOBE |
+        SF_LIGHT_POINT | SF_AREA_TRI | SF_AREA_DISK | SF_MANY_LIGHTS,
+    SF_ALL,
+};
+#endif
+constexpr int kNumShadeVariants = (int)(sizeof(kShadeVariants) / sizeof(kShadeVariants[0]));
 
 // render_tile's accumulation (craytracer.rs:175-188): per pixel, each sample batch is summed in
 // f64 in sample order, cast to f32 and added into the f32 film; batches in ascending order.

@@ -9,6 +9,25 @@
 namespace cray {
 
 // =============================================================================
+// Scene feature mask: what the uploaded scene can make k_shade do.  k_shade is instantiated for a handful of masks
+// (kShadeVariants, cray_kernels.h) and cray_scene_upload picks the leanest instantiation that covers the scene, so a
+// scene of constant-textured Lambert + conductor surfaces under one disk light does not carry the registers of the
+// image-texture, Oren-Nayar, glass, point/distant/infinite-light and sphere-emitter code.  A feature bit only removes
+// code the scene cannot reach: the arithmetic of what remains is untouched.
+// =============================================================================
+enum : uint32_t {
+    SF_TEX_CHECKER = 1u << 0, SF_TEX_IMAGE = 1u << 1,
+    SF_OREN_NAYAR = 1u << 2, SF_CONDUCTOR = 1u << 3, SF_SPEC_BRDF = 1u << 4, SF_SPEC_BTDF = 1u << 5, SF_FRESNEL_SPEC = 1u << 6,
+    SF_MULTI_LOBE = 1u << 7,        // some Material::BSDF holds a number of lobes other than one
+    SF_LIGHT_POINT = 1u << 8, SF_LIGHT_DISTANT = 1u << 9, SF_LIGHT_INFINITE = 1u << 10,
+    SF_AREA_TRI = 1u << 11, SF_AREA_SPHERE = 1u << 12, SF_AREA_DISK = 1u << 13,   // shapes of the area lights
+    SF_MANY_LIGHTS = 1u << 14,      // more than one light: LightSampler::sample has something to search
+    SF_HIT_TRI = 1u << 15, SF_HIT_SPHERE = 1u << 16, SF_HIT_DISK = 1u << 17,      // shapes a path can hit
+    SF_ALL = (1u << 18) - 1u
+};
+#define CRAY_HAS(F, bits) (((F) & (bits)) != 0u)
+
+// =============================================================================
 // Sampler: SipHash-1-3 pixel seed + Burley's Owen-scrambled Sobol
 // (src/sampling.rs:196-247 -> std DefaultHasher, sobol_burley 0.5.0)
 // =============================================================================
@@ -205,10 +224,11 @@ __device__ inline bool disk_hit(const cray_xf_shape& s, ray_t& ray, bool any_onl
 // hence the same bits the reference computed eagerly inside Shape::intersect.
 // need_uv = false leaves (u, v) of a sphere / disk hit at 0: for materials whose textures are all constant the
 // reference computes them (atan2, acos) and never looks at them.
+template <uint32_t F = SF_ALL>
 __device__ inline SurfPoint surface_at(const DevScene& sc, const cray_prim& pr, const ray_t& ray_in, double t, double bu, double bv, bool need_uv) {
     SurfPoint sp;
     sp.u = 0.0; sp.v = 0.0;
-    if (pr.shape_kind == CRAY_SHAPE_TRIANGLE) {
+    if (CRAY_HAS(F, SF_HIT_TRI) && (!CRAY_HAS(F, SF_HIT_SPHERE | SF_HIT_DISK) || pr.shape_kind == CRAY_SHAPE_TRIANGLE)) {
         const TriShade& ts = sc.tri_shade[pr.shape];
         sp.location = at(ray_in, t);
         sp.normal = unit(mk(ts.n0[0], ts.n0[1], ts.n0[2]) + mk(ts.n01[0], ts.n01[1], ts.n01[2]) * bu + mk(ts.n02[0], ts.n02[1], ts.n02[2]) * bv);
@@ -216,9 +236,10 @@ __device__ inline SurfPoint surface_at(const DevScene& sc, const cray_prim& pr, 
         sp.v = ts.uv0[1] + ts.uv01[1] * bu + ts.uv02[1] * bv;
         return sp;
     }
-    const cray_xf_shape& s = pr.shape_kind == CRAY_SHAPE_SPHERE ? sc.spheres[pr.shape] : sc.disks[pr.shape];
+    const bool is_sphere = CRAY_HAS(F, SF_HIT_SPHERE) && (!CRAY_HAS(F, SF_HIT_DISK) || pr.shape_kind == CRAY_SHAPE_SPHERE);
+    const cray_xf_shape& s = is_sphere ? sc.spheres[pr.shape] : sc.disks[pr.shape];
     vec3 oo = xf_point(s.inv, ray_in.o), od = xf_vector(s.inv, ray_in.d);
-    if (pr.shape_kind == CRAY_SHAPE_SPHERE) {
+    if (is_sphere) {
         vec3 loc = oo + od * t;
         if (need_uv) {
             double phi = atan2(loc.y, loc.x);
@@ -261,16 +282,18 @@ __device__ __forceinline__ bool tri_test(vec3 v0, vec3 e1, vec3 e2, const ray_t&
 
 // Shape::pdf_from (shape.rs:487-502): re-intersect the light's OWN shape from the shading
 // point; pdf = d^2 / (|w_i . n_x| * area) with n_x the *shading point's* normal (sic).
+template <uint32_t F = SF_ALL>
 __device__ inline double light_shape_pdf_from(const DevScene& sc, const DevLight& l, vec3 x, vec3 n_x, vec3 w_i) {
     ray_t ray = mkray(x, w_i);
     vec3 hit_location;
-    if (l.shape_kind == CRAY_SHAPE_TRIANGLE) {
+    if (CRAY_HAS(F, SF_AREA_TRI) && (!CRAY_HAS(F, SF_AREA_SPHERE | SF_AREA_DISK) || l.shape_kind == CRAY_SHAPE_TRIANGLE)) {
         double t, u, v;
         if (!tri_test(mk(l.v0[0], l.v0[1], l.v0[2]), mk(l.e1[0], l.e1[1], l.e1[2]), mk(l.e2[0], l.e2[1], l.e2[2]), ray, t, u, v)) return 0.0;
         hit_location = at(ray, t);
     } else {
         SurfPoint sp;
-        bool hit = l.shape_kind == CRAY_SHAPE_SPHERE ? sphere_hit(sc.spheres[l.shape], ray, false, &sp) : disk_hit(sc.disks[l.shape], ray, false, &sp);
+        const bool is_sphere = CRAY_HAS(F, SF_AREA_SPHERE) && (!CRAY_HAS(F, SF_AREA_DISK) || l.shape_kind == CRAY_SHAPE_SPHERE);
+        bool hit = is_sphere ? sphere_hit(sc.spheres[l.shape], ray, false, &sp) : disk_hit(sc.disks[l.shape], ray, false, &sp);
         if (!hit) return 0.0;
         hit_location = sp.location;
     }
@@ -280,12 +303,13 @@ __device__ inline double light_shape_pdf_from(const DevScene& sc, const DevLight
 }
 
 // Shape::sample (shape.rs:445-470)
+template <uint32_t F = SF_ALL>
 __device__ inline vec3 light_shape_sample(const DevScene& sc, const DevLight& l, double u, double v) {
-    if (l.shape_kind == CRAY_SHAPE_SPHERE) {
+    if (CRAY_HAS(F, SF_AREA_SPHERE) && (!CRAY_HAS(F, SF_AREA_TRI | SF_AREA_DISK) || l.shape_kind == CRAY_SHAPE_SPHERE)) {
         const cray_xf_shape& s = sc.spheres[l.shape];
         return xf_point(s.m, mk(0, 0, 0) + sample_sphere(u, v) * s.radius);
     }
-    if (l.shape_kind == CRAY_SHAPE_TRIANGLE) {
+    if (CRAY_HAS(F, SF_AREA_TRI) && (!CRAY_HAS(F, SF_AREA_DISK) || l.shape_kind == CRAY_SHAPE_TRIANGLE)) {
         double su = sqrt(u);  // sample_triangle, sampling.rs:51-55
         double b1 = 1.0 - su, b2 = v * su;
         return mk(l.v0[0], l.v0[1], l.v0[2]) + mk(l.e1[0], l.e1[1], l.e1[2]) * b1 + mk(l.e2[0], l.e2[1], l.e2[2]) * b2;
@@ -310,20 +334,22 @@ __device__ inline const uint8_t* image_texel(const DevScene& sc, const cray_text
     uint32_t y = to_u32_sat((double)(im.height - 1) * fv);
     return sc.pool + im.offset + 3ull * ((uint64_t)y * im.width + x);
 }
+template <uint32_t F = SF_ALL>
 __device__ inline rgb tex_color(const DevScene& sc, int32_t id, double u, double v) {
     const cray_texture& t = sc.textures[id];
-    if (t.kind == CRAY_TEX_CONSTANT) return mkc(t.a.r, t.a.g, t.a.b);
-    if (t.kind == CRAY_TEX_CHECKERBOARD) {
+    if (!CRAY_HAS(F, SF_TEX_CHECKER | SF_TEX_IMAGE) || t.kind == CRAY_TEX_CONSTANT) return mkc(t.a.r, t.a.g, t.a.b);
+    if (CRAY_HAS(F, SF_TEX_CHECKER) && (!CRAY_HAS(F, SF_TEX_IMAGE) || t.kind == CRAY_TEX_CHECKERBOARD)) {
         uint64_t uu = to_u64_sat(u * t.scale * 2.0), vv = to_u64_sat(v * t.scale * 2.0);
         return ((uu & 1) ^ (vv & 1)) == 0 ? mkc(t.a.r, t.a.g, t.a.b) : mkc(t.b.r, t.b.g, t.b.b);
     }
     const uint8_t* p = image_texel(sc, t, u, v);
     return mkc(sc.gamma_lut[p[0]], sc.gamma_lut[p[1]], sc.gamma_lut[p[2]]);  // == (c/255).powf(2.2) per lookup
 }
+template <uint32_t F = SF_ALL>
 __device__ inline double tex_scalar(const DevScene& sc, int32_t id, double u, double v) {
     const cray_texture& t = sc.textures[id];
-    if (t.kind == CRAY_TEX_CONSTANT) return t.a.r;
-    if (t.kind == CRAY_TEX_CHECKERBOARD) {
+    if (!CRAY_HAS(F, SF_TEX_CHECKER | SF_TEX_IMAGE) || t.kind == CRAY_TEX_CONSTANT) return t.a.r;
+    if (CRAY_HAS(F, SF_TEX_CHECKER) && (!CRAY_HAS(F, SF_TEX_IMAGE) || t.kind == CRAY_TEX_CHECKERBOARD)) {
         uint64_t uu = to_u64_sat(u * t.scale * 2.0), vv = to_u64_sat(v * t.scale * 2.0);
         return ((uu & 1) ^ (vv & 1)) == 0 ? t.a.r : t.b.r;
     }
@@ -388,10 +414,11 @@ __device__ __forceinline__ bool lobe_reflects(int kind) { return kind != CRAY_BX
 __device__ __forceinline__ bool lobe_transmits(int kind) { return kind == CRAY_BXDF_SPECULAR_BTDF || kind == CRAY_BXDF_FRESNEL_SPECULAR; }
 
 // BxDF::f (bxdf.rs:214-265)
+template <uint32_t F = SF_ALL>
 __device__ inline rgb lobe_f(const DevScene& sc, const cray_bxdf& bx, vec3 w_o, vec3 w_i, vec3 n, double u, double v) {
     const rgb zero = mkc(0, 0, 0);
-    if (bx.kind == CRAY_BXDF_LAMBERTIAN) return same_side(n, w_o, w_i) ? tex_color(sc, bx.tex_a, u, v) * kInvPi : zero;
-    if (bx.kind != CRAY_BXDF_OREN_NAYAR) return zero;
+    if (bx.kind == CRAY_BXDF_LAMBERTIAN) return same_side(n, w_o, w_i) ? tex_color<F>(sc, bx.tex_a, u, v) * kInvPi : zero;
+    if (!CRAY_HAS(F, SF_OREN_NAYAR) || bx.kind != CRAY_BXDF_OREN_NAYAR) return zero;
     if (!same_side(n, w_o, w_i)) return zero;
     double cos_i = fabs(dot(w_i, n)), cos_o = fabs(dot(w_o, n));
     double sin_i = sqrt(max_nn(1.0 - cos_i * cos_i, 0.0)), sin_o = sqrt(max_nn(1.0 - cos_o * cos_o, 0.0));
@@ -406,11 +433,11 @@ __device__ inline rgb lobe_f(const DevScene& sc, const cray_bxdf& bx, vec3 w_o, 
     double sin_alpha, tan_beta;
     if (cos_i > cos_o) { sin_alpha = sin_o; tan_beta = sin_i / cos_i; }
     else { sin_alpha = sin_i; tan_beta = sin_o / cos_o; }
-    double sigma = deg2rad(tex_scalar(sc, bx.tex_b, u, v));
+    double sigma = deg2rad(tex_scalar<F>(sc, bx.tex_b, u, v));
     double s2 = sigma * sigma;
     double A = 1.0 - s2 / (2.0 * (s2 + 0.33));
     double B = 0.45 * s2 / (s2 + 0.09);
-    return tex_color(sc, bx.tex_a, u, v) * (A + B * max_cos * sin_alpha * tan_beta) * kInvPi;
+    return tex_color<F>(sc, bx.tex_a, u, v) * (A + B * max_cos * sin_alpha * tan_beta) * kInvPi;
 }
 // BxDF::pdf (bxdf.rs:269-284); false = Pdf::Delta
 __device__ __forceinline__ bool lobe_pdf(const cray_bxdf& bx, vec3 w_i, vec3 n, double& pdf) {
@@ -421,64 +448,64 @@ __device__ __forceinline__ bool lobe_pdf(const cray_bxdf& bx, vec3 w_i, vec3 n, 
     return false;
 }
 // BxDF::sample (bxdf.rs:83-209); false = None
+template <uint32_t F = SF_ALL>
 __device__ inline bool lobe_sample(const DevScene& sc, const cray_bxdf& bx, double s0, double s1, vec3 w_o, vec3 n, double u, double v, LobeSample& out) {
     const rgb one = mkc(1, 1, 1);
-    switch (bx.kind) {
-    case CRAY_BXDF_LAMBERTIAN:
-    case CRAY_BXDF_OREN_NAYAR: {
+    constexpr uint32_t kSpecular = SF_CONDUCTOR | SF_SPEC_BRDF | SF_SPEC_BTDF | SF_FRESNEL_SPEC;
+    if (!CRAY_HAS(F, kSpecular) || bx.kind == CRAY_BXDF_LAMBERTIAN || bx.kind == CRAY_BXDF_OREN_NAYAR) {
         vec3 w_i = cosine_hemisphere(s0, s1, n);
         if (dot(n, w_o) < 0.0) w_i = flip(w_i);
         out.w_i = w_i;
-        out.f = lobe_f(sc, bx, w_o, w_i, n, u, v);
+        out.f = lobe_f<F>(sc, bx, w_o, w_i, n, u, v);
         out.delta = !lobe_pdf(bx, w_i, n, out.pdf);
         out.specular = false;
         return true;
     }
-    case CRAY_BXDF_FRESNEL_CONDUCTOR: {
+    if (CRAY_HAS(F, SF_CONDUCTOR) && (!CRAY_HAS(F, kSpecular & ~SF_CONDUCTOR) || bx.kind == CRAY_BXDF_FRESNEL_CONDUCTOR)) {
         double c = fabs(dot(w_o, n));
         out.w_i = reflect(w_o, n);
-        out.f = fresnel_conductor(one, tex_color(sc, bx.tex_a, u, v), tex_color(sc, bx.tex_b, u, v), c) / c;
+        out.f = fresnel_conductor(one, tex_color<F>(sc, bx.tex_a, u, v), tex_color<F>(sc, bx.tex_b, u, v), c) / c;
         out.delta = true; out.pdf = 0.0; out.specular = true;
         return true;
     }
-    case CRAY_BXDF_SPECULAR_BRDF: {
+    if (CRAY_HAS(F, SF_SPEC_BRDF) && (!CRAY_HAS(F, SF_SPEC_BTDF | SF_FRESNEL_SPEC) || bx.kind == CRAY_BXDF_SPECULAR_BRDF)) {
         double c = fabs(dot(w_o, n));
         rgb fr = bx.fresnel_kind == CRAY_FRESNEL_DIELECTRIC
                      ? one * fresnel_dielectric(bx.eta_i, bx.eta_t, c)
                      : fresnel_conductor(mkc(bx.c_eta_i.r, bx.c_eta_i.g, bx.c_eta_i.b), mkc(bx.c_eta_t.r, bx.c_eta_t.g, bx.c_eta_t.b),
                                          mkc(bx.c_k.r, bx.c_k.g, bx.c_k.b), c);
         out.w_i = reflect(w_o, n);
-        out.f = tex_color(sc, bx.tex_a, u, v) * fr / fabs(c);
+        out.f = tex_color<F>(sc, bx.tex_a, u, v) * fr / fabs(c);
         out.delta = true; out.pdf = 0.0; out.specular = true;
         return true;
     }
-    case CRAY_BXDF_SPECULAR_BTDF: {
+    if (CRAY_HAS(F, SF_SPEC_BTDF) && (!CRAY_HAS(F, SF_FRESNEL_SPEC) || bx.kind == CRAY_BXDF_SPECULAR_BTDF)) {
         double c = fabs(dot(w_o, n));
         vec3 w_i;
         if (!refract(w_o, n, c, bx.eta_i, bx.eta_t, w_i)) return false;
         double fr = fresnel_dielectric(bx.eta_i, bx.eta_t, c);
         out.w_i = w_i;
-        out.f = tex_color(sc, bx.tex_a, u, v) * (1.0 - fr) / c;
+        out.f = tex_color<F>(sc, bx.tex_a, u, v) * (1.0 - fr) / c;
         out.delta = true; out.pdf = 0.0; out.specular = true;
         return true;
     }
-    default: {  // FresnelSpecularBxDF
+    if (CRAY_HAS(F, SF_FRESNEL_SPEC)) {  // FresnelSpecularBxDF
         double c = dot(w_o, n);
-        double F = fresnel_dielectric(bx.eta_i, bx.eta_t, c);
-        if (s0 < F) {
+        double Fr = fresnel_dielectric(bx.eta_i, bx.eta_t, c);
+        if (s0 < Fr) {
             out.w_i = reflect(w_o, n);
-            out.f = tex_color(sc, bx.tex_a, u, v) * F / fabs(c);
-            out.delta = false; out.pdf = F; out.specular = true;
+            out.f = tex_color<F>(sc, bx.tex_a, u, v) * Fr / fabs(c);
+            out.delta = false; out.pdf = Fr; out.specular = true;
             return true;
         }
         vec3 w_i;
         if (!refract(w_o, n, c, bx.eta_i, bx.eta_t, w_i)) return false;
         out.w_i = w_i;
-        out.f = tex_color(sc, bx.tex_b, u, v) * (1.0 - F) / fabs(c);
-        out.delta = false; out.pdf = 1.0 - F; out.specular = true;
+        out.f = tex_color<F>(sc, bx.tex_b, u, v) * (1.0 - Fr) / fabs(c);
+        out.delta = false; out.pdf = 1.0 - Fr; out.specular = true;
         return true;
     }
-    }
+    return false;  // unreachable for a scene inside the mask
 }
 
 // material < 0 is the black matte of an AreaLightPrimitive (primitive.rs:40-46): a Lambertian lobe
@@ -496,19 +523,22 @@ __device__ inline bool material_has_diffuse_lobe(const DevScene& sc, int32_t mat
     return false;
 }
 
+template <uint32_t F = SF_ALL>
 __device__ inline rgb material_f(const DevScene& sc, int32_t mat, vec3 w_o, vec3 w_i, vec3 n, double u, double v) {
     const rgb zero = mkc(0, 0, 0);
     if (mat < 0) return same_side(n, w_o, w_i) ? zero * kInvPi : zero;
     const cray_material& m = sc.materials[mat];
-    if (!m.is_bsdf) return lobe_f(sc, sc.bxdfs[m.first_bxdf], w_o, w_i, n, u, v);
+    if (!m.is_bsdf) return lobe_f<F>(sc, sc.bxdfs[m.first_bxdf], w_o, w_i, n, u, v);
     bool reflecting = dot(w_o, n) * dot(w_i, n) > 0.0;  // bsdf.rs:60
     rgb f = zero;
-    for (int i = 0; i < m.n_bxdfs; i++) {
+    const int nb = CRAY_HAS(F, SF_MULTI_LOBE) ? m.n_bxdfs : 1;
+    for (int i = 0; i < nb; i++) {
         const cray_bxdf& bx = sc.bxdfs[m.first_bxdf + i];
-        if (reflecting ? lobe_reflects(bx.kind) : lobe_transmits(bx.kind)) f = f + lobe_f(sc, bx, w_o, w_i, n, u, v);
+        if (reflecting ? lobe_reflects(bx.kind) : lobe_transmits(bx.kind)) f = f + lobe_f<F>(sc, bx, w_o, w_i, n, u, v);
     }
     return f;
 }
+template <uint32_t F = SF_ALL>
 __device__ inline bool material_pdf(const DevScene& sc, int32_t mat, vec3 w_o, vec3 w_i, vec3 n, double& pdf) {
     if (mat < 0) { pdf = kInvPi * fabs(dot(w_i, n)); return true; }
     const cray_material& m = sc.materials[mat];
@@ -516,7 +546,8 @@ __device__ inline bool material_pdf(const DevScene& sc, int32_t mat, vec3 w_o, v
     bool reflecting = dot(w_o, n) * dot(w_i, n) > 0.0;
     double acc = 0.0;
     int matching = 0;
-    for (int i = 0; i < m.n_bxdfs; i++) {
+    const int nb = CRAY_HAS(F, SF_MULTI_LOBE) ? m.n_bxdfs : 1;
+    for (int i = 0; i < nb; i++) {
         const cray_bxdf& bx = sc.bxdfs[m.first_bxdf + i];
         if (!(reflecting ? lobe_reflects(bx.kind) : lobe_transmits(bx.kind))) continue;
         double p;
@@ -526,6 +557,7 @@ __device__ inline bool material_pdf(const DevScene& sc, int32_t mat, vec3 w_o, v
     return false;
 }
 // Material::sample / BSDF::sample (material.rs:72-83, bsdf.rs:15-55)
+template <uint32_t F = SF_ALL>
 __device__ inline bool material_sample(const DevScene& sc, int32_t mat, double s1d, double s0, double s1, vec3 w_o, vec3 n, double u, double v, LobeSample& out) {
     if (mat < 0) {
         vec3 w_i = cosine_hemisphere(s0, s1, n);
@@ -536,11 +568,17 @@ __device__ inline bool material_sample(const DevScene& sc, int32_t mat, double s
         return true;
     }
     const cray_material& m = sc.materials[mat];
-    if (!m.is_bsdf) return lobe_sample(sc, sc.bxdfs[m.first_bxdf], s0, s1, w_o, n, u, v, out);
+    if (!m.is_bsdf) return lobe_sample<F>(sc, sc.bxdfs[m.first_bxdf], s0, s1, w_o, n, u, v, out);
+    if (!CRAY_HAS(F, SF_MULTI_LOBE)) {
+        // every BSDF of the scene holds exactly one lobe: pick = floor(u * 1) = 0 (u < 1), nothing to add, pdf / 1.0
+        if (!lobe_sample<F>(sc, sc.bxdfs[m.first_bxdf], s0, s1, w_o, n, u, v, out)) return false;
+        if (!out.delta) out.pdf = out.pdf / 1.0;
+        return true;
+    }
     if (m.n_bxdfs == 0) return false;
     int pick = (int)to_u64_sat(s1d * (double)m.n_bxdfs);
     LobeSample s;
-    if (!lobe_sample(sc, sc.bxdfs[m.first_bxdf + pick], s0, s1, w_o, n, u, v, s)) return false;
+    if (!lobe_sample<F>(sc, sc.bxdfs[m.first_bxdf + pick], s0, s1, w_o, n, u, v, s)) return false;
     if (s.delta) { out = s; return true; }  // Delta samples are returned unscaled (bsdf.rs:51-53)
     double pdf = s.pdf;
     rgb f = s.f;
@@ -548,7 +586,7 @@ __device__ inline bool material_sample(const DevScene& sc, int32_t mat, double s
     for (int i = 0; i < m.n_bxdfs; i++) {
         const cray_bxdf& other = sc.bxdfs[m.first_bxdf + i];
         if (i == pick || !(reflecting ? lobe_reflects(other.kind) : lobe_transmits(other.kind))) continue;
-        f = f + lobe_f(sc, other, w_o, s.w_i, n, u, v);
+        f = f + lobe_f<F>(sc, other, w_o, s.w_i, n, u, v);
         double op;
         if (lobe_pdf(other, s.w_i, n, op)) pdf += op;
     }
@@ -569,7 +607,9 @@ __device__ __forceinline__ int total_order(double a, double b) {  // f64::total_
     return x < y ? -1 : (x > y ? 1 : 0);
 }
 // LightSampler::sample (:203-211): binary search, exact match -> that index, else insertion point
+template <uint32_t F = SF_ALL>
 __device__ inline uint32_t light_select(const DevScene& sc, double u, double& pdf) {
+    if (!CRAY_HAS(F, SF_MANY_LIGHTS)) { pdf = light_select_pdf(sc, 0); return 0; }  // one light: the search ends at index 0 for every u
     uint32_t lo = 0, hi = sc.n_lights, idx = 0;
     bool found = false;
     while (lo < hi) {

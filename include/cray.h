@@ -123,6 +123,7 @@ typedef struct {
     double trace_mixed_ms;                  /* launches that trace the shadow rays of bounce b together with the
                                                path segments of bounce b+1 (not used with count_traversal) */
     uint32_t trace_mixed_launches, pad2_;
+    uint64_t closest_hits;                  /* of closest_rays: segments that hit a primitive (the paths k_shade shades fully) */
 } cray_stats;
 
 /* test hook: batched Scene::intersect / Scene::intersects */
