@@ -97,7 +97,10 @@ def lib():
         return _lib
     so = _build.SO
     BUILD_MODE = 'shipped'
-    if _build.stale():
+    if os.environ.get('CRAY_LIB'):   # A/B experiments: load this build of the library instead (never rebuilt here)
+        so = os.environ['CRAY_LIB']
+        BUILD_MODE = 'override:' + so
+    elif _build.stale():
         try:
             _build.build()
             BUILD_MODE = 'rebuilt'
