@@ -329,14 +329,70 @@ extern "C" int cray_scene_upload(cray_ctx* c, const cray_flat_scene* f, cray_sce
     if (f->n_prims >= (1u << 28)) { set_last_error("too many primitives for the 28-bit leaf slot index"); return CRAY_ERR_UNSUPPORTED; }
     HIP_TRY(hipSetDevice(c->device));
 
-    // ---- leaf slots in leaf order; interior records with both children's bounds
+    // ---- storage order of the interior records and of the leaf slots.  Traversal order is defined by the child
+    // references, so any order gives the same hits and counters; only locality differs.  Default: the flat scene's DFS
+    // pre-order for the records and leaf (prim_refs) order for the slots.  CRAY_BVH_LAYOUT=<treelet>[:<top>] (experiments,
+    // profiles/r02_experiments.md): the first <top> records breadth-first from the root, then treelets of <treelet>
+    // records (breadth-first inside a treelet, treelets depth-first), leaf slots in the order the records reference them.
+    uint32_t lay_treelet = 0, lay_top = 0;
+    if (const char* ev = getenv("CRAY_BVH_LAYOUT")) {
+        lay_treelet = (uint32_t)strtoul(ev, nullptr, 10);
+        if (const char* c2 = strchr(ev, ':')) lay_top = (uint32_t)strtoul(c2 + 1, nullptr, 10);
+    }
+    for (uint32_t i = 0; i < f->n_nodes; i++) {
+        const cray_bvh_node& nd = f->nodes[i];
+        if (!nd.is_leaf && (nd.left >= f->n_nodes || nd.right >= f->n_nodes || nd.axis < 0 || nd.axis > 2)) { set_last_error("BVH node %u malformed", i); return CRAY_ERR_INVALID; }
+        if (nd.is_leaf) {
+            if (nd.count < 1 || nd.count > 8) { set_last_error("BVH leaf with %u primitives (supported: 1..8)", nd.count); return CRAY_ERR_UNSUPPORTED; }
+            if ((uint64_t)nd.first + nd.count > f->n_prim_refs) { set_last_error("BVH leaf range out of bounds"); return CRAY_ERR_INVALID; }
+        }
+    }
+    std::vector<uint32_t> inner_index(f->n_nodes, kNoRef);   // flat node -> interior record
+    std::vector<uint32_t> leaf_first(f->n_nodes, kNoRef);    // flat leaf node -> first slot
+    uint32_t n_inner = 0, n_slots = 0;
+    if (lay_treelet == 0) {
+        for (uint32_t i = 0; i < f->n_nodes; i++) {
+            if (!f->nodes[i].is_leaf) inner_index[i] = n_inner++;
+            else leaf_first[i] = f->nodes[i].first;
+        }
+        n_slots = f->n_prim_refs;
+    } else {
+        std::vector<uint32_t> roots, fifo;
+        if (!f->nodes[0].is_leaf) roots.push_back(0);
+        else { leaf_first[0] = 0; n_slots = f->nodes[0].count; }
+        bool first = true;
+        while (!roots.empty()) {
+            const uint32_t r = roots.back();
+            roots.pop_back();
+            const uint32_t budget = first && lay_top ? lay_top : lay_treelet;
+            first = false;
+            fifo.clear();
+            fifo.push_back(r);
+            size_t head = 0;
+            uint32_t taken = 0;
+            while (head < fifo.size() && taken < budget) {
+                const uint32_t nidx = fifo[head++];
+                if (inner_index[nidx] != kNoRef) { set_last_error("BVH is not a tree (node %u reached twice)", nidx); return CRAY_ERR_INVALID; }
+                inner_index[nidx] = n_inner++;
+                taken++;
+                for (uint32_t ch : {f->nodes[nidx].left, f->nodes[nidx].right}) {
+                    if (!f->nodes[ch].is_leaf) fifo.push_back(ch);
+                    else if (leaf_first[ch] == kNoRef) { leaf_first[ch] = n_slots; n_slots += f->nodes[ch].count; }
+                }
+            }
+            for (size_t k = fifo.size(); k > head; k--) roots.push_back(fifo[k - 1]);  // the frontier: next treelets, leftmost first
+        }
+        if (n_slots != f->n_prim_refs) { set_last_error("BVH leaves cover %u of %u primitive references", n_slots, f->n_prim_refs); return CRAY_ERR_INVALID; }
+    }
+
+    // ---- leaf slots; interior records with both children's bounds
     std::vector<LeafSlot> slots((size_t)f->n_prim_refs + 1);  // +1: the unified 112-B record fetch of k_trace reads past an 80-B slot
     memset(&slots[f->n_prim_refs], 0, sizeof(LeafSlot));
-    for (uint32_t i = 0; i < f->n_prim_refs; i++) {
-        uint32_t pi = f->prim_refs[i];
-        if (pi >= f->n_prims) { set_last_error("prim_refs[%u] out of range", i); return CRAY_ERR_INVALID; }
+    auto fill_slot = [&](uint32_t dst, uint32_t src_ref) -> int {
+        uint32_t pi = f->prim_refs[src_ref];
+        if (pi >= f->n_prims) { set_last_error("prim_refs[%u] out of range", src_ref); return CRAY_ERR_INVALID; }
         const cray_prim& p = f->prims[pi];
-        LeafSlot& s = slots[i];
+        LeafSlot& s = slots[dst];
         memset(&s, 0, sizeof(s));
         s.prim = pi;
         s.kind = (uint32_t)p.shape_kind;
@@ -351,26 +407,34 @@ extern "C" int cray_scene_upload(cray_ctx* c, const cray_flat_scene* f, cray_sce
             set_last_error("primitive %u: bad shape", pi);
             return CRAY_ERR_INVALID;
         }
+        return CRAY_OK;
+    };
+    if (lay_treelet == 0) {
+        for (uint32_t i = 0; i < f->n_prim_refs; i++) { int e0 = fill_slot(i, i); if (e0) return e0; }
+    } else {
+        for (uint32_t i = 0; i < f->n_nodes; i++) {
+            const cray_bvh_node& nd = f->nodes[i];
+            if (!nd.is_leaf) continue;
+            if (leaf_first[i] == kNoRef) { set_last_error("BVH leaf %u is not referenced", i); return CRAY_ERR_INVALID; }
+            for (uint32_t k = 0; k < nd.count; k++) { int e0 = fill_slot(leaf_first[i] + k, nd.first + k); if (e0) return e0; }
+        }
     }
-    std::vector<uint32_t> inner_index(f->n_nodes, kNoRef);
-    uint32_t n_inner = 0;
-    for (uint32_t i = 0; i < f->n_nodes; i++)
-        if (!f->nodes[i].is_leaf) inner_index[i] = n_inner++;
     auto make_ref = [&](uint32_t node, uint32_t* ref) -> int {
         if (node >= f->n_nodes) { set_last_error("BVH child index %u out of range", node); return CRAY_ERR_INVALID; }
         const cray_bvh_node& nd = f->nodes[node];
-        if (!nd.is_leaf) { *ref = inner_index[node]; return CRAY_OK; }
-        if (nd.count < 1 || nd.count > 8) { set_last_error("BVH leaf with %u primitives (supported: 1..8)", nd.count); return CRAY_ERR_UNSUPPORTED; }
-        if ((uint64_t)nd.first + nd.count > f->n_prim_refs) { set_last_error("BVH leaf range out of bounds"); return CRAY_ERR_INVALID; }
-        *ref = kLeafBit | (nd.first << 3) | (nd.count - 1);
+        if (!nd.is_leaf) {
+            if (inner_index[node] == kNoRef) { set_last_error("BVH node %u is not reachable from the root", node); return CRAY_ERR_INVALID; }
+            *ref = inner_index[node];
+            return CRAY_OK;
+        }
+        *ref = kLeafBit | (leaf_first[node] << 3) | (nd.count - 1);
         return CRAY_OK;
     };
     std::vector<InnerNode> inner(n_inner ? n_inner : 1);
     memset(inner.data(), 0, inner.size() * sizeof(InnerNode));
     for (uint32_t i = 0; i < f->n_nodes; i++) {
         const cray_bvh_node& nd = f->nodes[i];
-        if (nd.is_leaf) continue;
-        if (nd.left >= f->n_nodes || nd.right >= f->n_nodes || nd.axis < 0 || nd.axis > 2) { set_last_error("BVH node %u malformed", i); return CRAY_ERR_INVALID; }
+        if (nd.is_leaf || inner_index[i] == kNoRef) continue;
         InnerNode& o = inner[inner_index[i]];
         const cray_bvh_node& l = f->nodes[nd.left];
         const cray_bvh_node& r = f->nodes[nd.right];
