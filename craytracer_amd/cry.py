@@ -143,7 +143,8 @@ def parse_scene(text, base_dir=None, width=0, height=0, num_samples=0, max_depth
         except Exception:
             return 1
 
-    cb = _LOADER_T(load)
+    # image_loader=None: no callback, the library decodes PNM / JPEG itself (cray_load_image, include/cray_io.h)
+    cb = _LOADER_T(load) if image_loader is not None else C.cast(None, _LOADER_T)
     ov = _COverrides(width, height, num_samples, max_depth)
     h, err = C.c_void_p(), _CErr()
     rc = L.cray_cry_parse_scene(text.encode('utf-8'), base_dir.encode('utf-8') if base_dir else None, cb, None,

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/cray_cry.h"
+#include "../../include/cray_io.h"
 
 namespace {
 
@@ -1000,7 +1001,8 @@ extern "C" int cray_cry_parse_scene(const char* input, const char* base_dir, cra
     std::unique_ptr<cray_owned_scene> os(new cray_owned_scene());
     Builder& b = os->b;
     b.base_dir = base_dir ? base_dir : "";
-    b.loader = loader; b.loader_user = loader_user;
+    b.loader = loader ? loader : cray_default_image_loader;   // no loader: PNM / JPEG through cray_load_image (cray_io.h)
+    b.loader_user = loader_user;
     if (!build_scene(top.map, b, e)) { set_err(err, e); return -1; }
     count_unused(top, b.warnings);
     if (ov) {

@@ -24,6 +24,17 @@ int cray_write_exr(const char* path, uint32_t width, uint32_t height, const floa
  * Call with rgb == NULL to get the size. */
 int cray_read_exr(const char* path, uint32_t* width, uint32_t* height, float* rgb, uint64_t capacity_floats);
 
+/* Texture files for hosts without an image library — what the reference does with the `image` crate
+ * (`image::io::Reader::open(path).decode()` + `.to_rgb8()`, src/obj.rs:16-24, src/texture.rs:57-58):
+ *   PNM (P6 / P3 / P5 / P2) and JPEG (8-bit Huffman: baseline, extended sequential and progressive; 1 or 3 components).
+ * JPEG arithmetic is the IJG reference decoder's (islow IDCT, fancy upsampling), i.e. libjpeg-turbo's pixels; the Rust
+ * jpeg-decoder may differ from it by a level or two.  *rgb8: malloc()-ed width*height*3 bytes, row-major; release with
+ * cray_free_image (or free).  Returns 0, CRAY_ERR_INVALID (unreadable / corrupt) or CRAY_ERR_UNSUPPORTED (other formats). */
+int cray_load_image(const char* path, uint32_t* width, uint32_t* height, uint8_t** rgb8);
+void cray_free_image(uint8_t* rgb8);
+/* The same as a cray_image_loader (cray_cry.h): cray_cry_parse_scene uses it when the caller passes no loader. */
+int cray_default_image_loader(const char* path, void* user, uint32_t* width, uint32_t* height, uint8_t** rgb8);
+
 #ifdef __cplusplus
 }
 #endif

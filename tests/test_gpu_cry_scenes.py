@@ -32,6 +32,34 @@ def test_parsed_scene_renders_pixel_exact(name, w, h, spp):
     ctx.close()
 
 
+def test_obj_mtl_mesh_renders_pixel_exact_through_the_library_s_own_image_decoder():
+    """mesh_room.cry -> `Mesh { file_name: 'meshes/room.obj' }` (tools/gen_mesh_fixture.py): OBJ + MTL with smooth normals,
+    UVs, a `map_Kd` PPM decoded by cray_load_image (no Python image loader in the path), `Ke` faces as per-triangle area
+    lights, a `d < 1` glass pane, an `illum 4` metal ball, plastics at Ns 0 / 250 / 1000 and an unknown `usemtl` ->
+    reader -> Scene::new mirror (BVH on the GPU) -> GPU render, against the oracle fed with the same description."""
+    base = os.path.dirname(GOLDEN)
+    sc = cry.load_scene_file(os.path.join(GOLDEN, 'mesh_room.cry'), base_dir=base, image_loader=None)
+    d = sc.desc()
+    assert d.n_triangles == 488 and d.n_lights == 13 and d.n_images == 1 and sc.warnings == 0
+    via_pillow = cry.load_scene_file(os.path.join(GOLDEN, 'mesh_room.cry'), base_dir=base)
+    pool = lambda s_: bytes(np.ctypeslib.as_array(backend.C.cast(s_.desc().image_pool, backend.C.POINTER(backend.C.c_uint8)), shape=(s_.desc().image_pool_bytes,)))
+    assert pool(sc) == pool(via_pillow)
+    ctx = backend.Context(0)
+    dev = ctx.upload(backend.HostScene(sc, bvh_ctx=ctx))
+    orc = ol.OracleScene(sc)
+    for seed in (0, 11):
+        g, gst = dev.render(seed=seed, count_traversal=True)
+        o, ost = orc.render(seed=seed)
+        for k in ('closest_rays', 'shadow_rays', 'closest_nodes', 'closest_prims', 'shadow_nodes', 'shadow_prims'):
+            assert gst[k] == ost[k], k
+        assert np.array_equal(g, o) and gst['nonfinite'] == 0
+    t, _ = dev.render(seed=0)                   # the timed configuration
+    o, _ = orc.render(seed=0)
+    assert np.array_equal(t, o) and o.mean() > 0.05
+    dev.close()
+    ctx.close()
+
+
 def test_command_line_writes_the_same_film_as_exr(tmp_path):
     """`python -m craytracer_amd --scene .. --output out.exr` (the reference's CLI, craytracer.rs:321-370): the EXR
     on disk holds exactly the film the library returns, which is the oracle's."""
