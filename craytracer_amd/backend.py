@@ -82,7 +82,7 @@ ABI_SYMBOLS = ['cray_ctx_create', 'cray_ctx_destroy', 'cray_scene_upload', 'cray
                'cray_cry_parse_scene', 'cray_owned_scene_desc', 'cray_owned_scene_warnings', 'cray_owned_scene_free',
                'cray_scene_info', 'cray_comm_unique_id', 'cray_comm_init', 'cray_comm_rank', 'cray_comm_world_size',
                'cray_comm_barrier', 'cray_comm_allreduce_f64', 'cray_scene_broadcast', 'cray_render_gather',
-               'cray_film_gather', 'cray_film_pack', 'cray_film_unpack', 'cray_measure_stream_read', 'cray_load_image', 'cray_free_image', 'cray_default_image_loader']
+               'cray_film_gather', 'cray_film_pack', 'cray_film_unpack', 'cray_measure_stream_read', 'cray_load_image', 'cray_free_image', 'cray_default_image_loader', 'cray_set_sobol_vectors']
 
 _lib = None
 #: how the loaded library came to be: 'shipped' (the .so in the tree was current), 'rebuilt' (sources were newer, hipcc ran),
@@ -153,6 +153,7 @@ def lib():
     L.cray_load_image.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_void_p)]
     L.cray_free_image.restype = None
     L.cray_free_image.argtypes = [C.c_void_p]
+    L.cray_set_sobol_vectors.argtypes = [C.c_void_p]
     L.cray_measure_stream_read.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_double)]
     L.cray_film_unpack.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
     L.cray_host_scene_flat.restype = C.POINTER(FlatScene)
@@ -425,6 +426,16 @@ def write_exr(path, film):
     img = np.ascontiguousarray(film, dtype=np.float32)
     assert img.ndim == 3 and img.shape[2] == 3
     _check(lib().cray_write_exr(os.fsencode(path), img.shape[1], img.shape[0], img.ctypes.data), 'cray_write_exr')
+
+
+def set_sobol_vectors(table):
+    """cray_set_sobol_vectors: uint16 [64, 16, 4] (sobol_burley REV_VECTORS layout) for scenes uploaded afterwards; None = built-in."""
+    if table is None:
+        _check(lib().cray_set_sobol_vectors(None), 'cray_set_sobol_vectors')
+        return
+    t = np.ascontiguousarray(table, dtype=np.uint16)
+    assert t.shape == (64, 16, 4)
+    _check(lib().cray_set_sobol_vectors(t.ctypes.data), 'cray_set_sobol_vectors')
 
 
 def load_image(path):

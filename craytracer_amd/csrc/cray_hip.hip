@@ -311,6 +311,17 @@ extern "C" void cray_scene_info(const cray_scene* s, uint32_t* w, uint32_t* h, u
     if (depth) *depth = s->dev.max_depth;
 }
 
+// Direction vectors every later cray_scene_upload copies to the device: the built-in table or the caller's
+// (cray_set_sobol_vectors).
+static uint16_t g_sobol_override[CRAY_SOBOL_SETS * CRAY_SOBOL_BITS * 4];
+static const uint16_t* g_sobol_table = &CRAY_SOBOL_REV_VECTORS[0][0][0];
+extern "C" int cray_set_sobol_vectors(const uint16_t* rev_vectors) {
+    if (!rev_vectors) { g_sobol_table = &CRAY_SOBOL_REV_VECTORS[0][0][0]; return CRAY_OK; }
+    memcpy(g_sobol_override, rev_vectors, sizeof(g_sobol_override));
+    g_sobol_table = g_sobol_override;
+    return CRAY_OK;
+}
+
 // the leanest instantiation of k_shade that covers `features`
 static int pick_shade_variant(uint32_t features) {
     int best = kNumShadeVariants - 1;
@@ -571,7 +582,7 @@ extern "C" int cray_scene_upload(cray_ctx* c, const cray_flat_scene* f, cray_sce
     if (!e) e = upload(s, lights.data(), lights.size(), &d.lights);
     if (!e) e = upload(s, f->light_cdf, (size_t)f->n_lights, &d.light_cdf);
     if (!e) e = upload(s, f->first_equal_light, (size_t)f->n_lights, &d.first_equal_light);
-    if (!e) e = upload(s, &CRAY_SOBOL_REV_VECTORS[0][0][0], (size_t)CRAY_SOBOL_SETS * CRAY_SOBOL_BITS * 4, &d.sobol);
+    if (!e) e = upload(s, g_sobol_table, (size_t)CRAY_SOBOL_SETS * CRAY_SOBOL_BITS * 4, &d.sobol);
     if (e) { cray_scene_free(s); return e; }
     // what this scene can make k_shade do -> the leanest instantiation that covers it
     uint32_t feat = 0;

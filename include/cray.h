@@ -150,6 +150,13 @@ uint64_t cray_scene_device_bytes(const cray_scene* scene);
 /* Film size, Scene.num_samples and Scene.max_depth of an uploaded (or broadcast-received) scene; any pointer may be NULL. */
 void cray_scene_info(const cray_scene* scene, uint32_t* film_width, uint32_t* film_height, uint32_t* num_samples, uint32_t* max_depth);
 
+/* The sampler's direction numbers (src/sampling.rs:196-247 -> sobol_burley 0.5.0, Cargo.lock:1019; the crate's source is
+ * not part of the reference tree).  The built-in table is the bit-reversed 16-bit form of Joe & Kuo's
+ * new-joe-kuo-6.21201 direction numbers for the first 256 dimensions; whether the crate embeds exactly this set cannot be
+ * verified offline.  A host that has the crate can hand over its `REV_VECTORS` ([64 sets][16 bits][4 lanes] u16): scenes
+ * uploaded afterwards sample with it.  NULL restores the built-in table.  Process-wide; call before cray_scene_upload. */
+int cray_set_sobol_vectors(const uint16_t* rev_vectors /* 64 * 16 * 4 */);
+
 /* Replaces `render` (craytracer.rs:224): fills out_rgb[W*H*3]. */
 int cray_render(cray_ctx* ctx, cray_scene* scene, const cray_render_params* params, float* out_rgb,
                 cray_stats* stats);

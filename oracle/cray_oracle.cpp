@@ -140,8 +140,12 @@ static inline float u32_to_f32_norm(uint32_t n) {
     memcpy(&f, &bits, 4);
     return f - 1.0f;
 }
+/* orc_set_sobol_vectors: a holder of the sobol_burley crate can load its own REV_VECTORS (the built-in table is scipy's
+ * new-joe-kuo-6.21201, bit-reversed; whether the crate ships the same Joe-Kuo set cannot be checked offline). */
+static uint16_t g_sobol_override[CRAY_SOBOL_SETS][CRAY_SOBOL_BITS][4];
+static const uint16_t (*g_sobol_table)[CRAY_SOBOL_BITS][4] = CRAY_SOBOL_REV_VECTORS;
 static void sobol_sample_4d(uint32_t sample_index, uint32_t dimension_set, uint32_t seed, float out[4]) {
-    const uint16_t(*vecs)[4] = CRAY_SOBOL_REV_VECTORS[dimension_set];
+    const uint16_t(*vecs)[4] = g_sobol_table[dimension_set];
     uint32_t shuffled_rev_index = sb_scramble_core(reverse_bits32(sample_index), sb_hash(seed));
     uint32_t sob[4] = {0, 0, 0, 0};
     uint32_t index = shuffled_rev_index & 0xffff0000u; /* top 16 bits only */
@@ -1517,6 +1521,12 @@ void orc_camera_ray(void* s, uint64_t seed, uint32_t x, uint32_t y, uint32_t sam
 
 /* 0: correctly rounded sin/cos in the sampling functions (default); 1: platform libm */
 void orc_set_libm_mode(int mode) { g_libm_mode = mode; }
+/* 64 x 16 x 4 bit-reversed direction vectors (sobol_burley's REV_VECTORS layout); NULL restores the built-in table */
+void orc_set_sobol_vectors(const uint16_t* v) {
+    if (!v) { g_sobol_table = CRAY_SOBOL_REV_VECTORS; return; }
+    memcpy(g_sobol_override, v, sizeof(g_sobol_override));
+    g_sobol_table = g_sobol_override;
+}
 double orc_sample_sin(double x) { return sample_sin(x); }
 double orc_sample_cos(double x) { return sample_cos(x); }
 

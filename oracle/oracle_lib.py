@@ -89,6 +89,7 @@ def lib():
         L.orc_partition_by.restype = C.c_uint64
         L.orc_partition_by.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int64, C.c_int64]
         L.orc_set_libm_mode.argtypes = [C.c_int]
+        L.orc_set_sobol_vectors.argtypes = [C.c_void_p]
         L.orc_sample_sin.restype = C.c_double
         L.orc_sample_sin.argtypes = [C.c_double]
         L.orc_sample_cos.restype = C.c_double
@@ -101,6 +102,16 @@ def lib():
 def set_libm_mode(mode):
     """0: correctly rounded sin/cos in the sampling functions (default); 1: platform libm."""
     lib().orc_set_libm_mode(mode)
+
+
+def set_sobol_vectors(table):
+    """uint16 [64, 16, 4] bit-reversed direction vectors (sobol_burley REV_VECTORS layout), or None for the built-in table."""
+    if table is None:
+        lib().orc_set_sobol_vectors(None)
+        return
+    t = np.ascontiguousarray(table, dtype=np.uint16)
+    assert t.shape == (64, 16, 4)
+    lib().orc_set_sobol_vectors(t.ctypes.data)
 
 
 def _f64(a):
