@@ -1,0 +1,25 @@
+#!/bin/bash
+# tools/profile_round.sh <tag> [workload]: the rocprofv3 evidence of a round, on the GPU box.
+#   1. --kernel-trace --stats over the default bench command (3 timed frames): per-kernel average duration
+#   2. --pmc FETCH_SIZE and --pmc WRITE_SIZE, each in its OWN pass (TCC slots: 3 + 2 of 4) over one frame: HBM traffic
+#   3. --pmc SQ pass (lane utilisation, waits) and a TCC hit-rate pass over one frame
+# Counter passes never carry trace options other than the implicit kernel dispatch records (gpurun refuses mixes).
+# Results: gpurun_out/prof_<tag>/{kernel_stats.csv,pmc_*.csv,bench.log}; copy what should be judged into profiles/.
+set -e
+tag=$1; wl=${2:-dragon}
+root=$(cd "$(dirname "$0")/.." && pwd)
+cd "$root"
+out=gpurun_out/prof_$tag
+mkdir -p $out
+export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o run -- python3 bench.py --workload $wl --steps 3 --warmup 1 --cpu-baseline 0 > $out/bench.log 2> $out/stats.log
+cp $(find $out/stats -name '*kernel_stats.csv' | head -1) $out/kernel_stats.csv
+for pass in "fetch_size:FETCH_SIZE" "write_size:WRITE_SIZE" "sq:SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU" "tcc:TCC_HIT_sum TCC_MISS_sum" "ta:TA_TA_BUSY_sum GRBM_GUI_ACTIVE"; do
+  name=${pass%%:*}; ctrs=${pass#*:}
+  rocprofv3 --pmc $ctrs --output-format csv -d $out/pmc_$name -o run -- python3 bench.py --workload $wl --steps 1 --warmup 0 --cpu-baseline 0 --count-pass 0 > $out/pmc_$name.bench.log 2> $out/pmc_$name.log || echo "pass $name failed" >> $out/failed.txt
+  f=$(find $out/pmc_$name -name '*counter_collection.csv' | head -1)
+  [ -n "$f" ] && cp $f $out/pmc_$name.csv
+  rm -rf $out/pmc_$name
+done
+rm -rf $out/stats
+ls -la $out

@@ -18,7 +18,7 @@ FETCH_CORRECTION = 2.0
 def per_kernel(csv, counter):
     df = pd.read_csv(csv)
     df = df[df['Counter_Name'] == counter]
-    df['k'] = df['Kernel_Name'].str.extract(r'(k_\w+(?:<\w+, \w+>)?)')
+    df['k'] = df['Kernel_Name'].str.extract(r'(k_\w+(?:<[^>]*>)?)')
     g = df.groupby('k')['Counter_Value']
     return g.sum().to_dict(), g.count().to_dict()
 
@@ -29,7 +29,14 @@ if __name__ == '__main__':
     path = os.path.join(root, 'profiles', 'hbm_traffic.json')
     data = json.load(open(path)) if os.path.exists(path) else {}
     fs, fc = per_kernel(fetch_csv, 'FETCH_SIZE')
-    entry = {'source': os.path.relpath(fetch_csv, root), 'fetch_correction': FETCH_CORRECTION, 'kernels': {}}
+    import subprocess
+    try:
+        git = subprocess.check_output(['git', 'rev-parse', '--short', 'HEAD'], cwd=root, text=True).strip()
+        dirty = bool(subprocess.check_output(['git', 'status', '--porcelain', '--', 'craytracer_amd/csrc'], cwd=root, text=True).strip())
+        git += '+dirty' if dirty else ''
+    except Exception:
+        git = None
+    entry = {'source': os.path.relpath(fetch_csv, root), 'git': git, 'fetch_correction': FETCH_CORRECTION, 'kernels': {}}
     for k in fs:
         entry['kernels'][k] = {'launches': int(fc[k]), 'fetch_bytes_per_launch': fs[k] * 1024 * FETCH_CORRECTION / fc[k]}
     if len(sys.argv) > 3:
