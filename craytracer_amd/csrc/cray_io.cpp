@@ -98,11 +98,14 @@ extern "C" int cray_read_exr(const char* path, uint32_t* w_out, uint32_t* h_out,
         if (name == "dataWindow" && sz == 16) { x0 = rd_i32(p); y0 = rd_i32(p + 4); x1 = rd_i32(p + 8); y1 = rd_i32(p + 12); }
         if (name == "compression" && sz == 1) compression = d[p];
         if (name == "channels") {
+            const size_t end = p + (size_t)sz;   // every read below stays inside the attribute
             size_t q = p;
-            while (q < p + (size_t)sz && d[q]) {
+            while (q < end && d[q]) {
                 std::string cn;
-                while (d[q]) cn.push_back((char)d[q++]);
+                while (q < end && d[q]) cn.push_back((char)d[q++]);
+                if (q >= end) return fail("truncated channel list");
                 q++;
+                if (q + 16 > end) return fail("truncated channel list");
                 if (rd_i32(q) != 2) return fail("channel is not FLOAT");
                 q += 16;
                 chans += cn; chans += ',';
@@ -114,6 +117,8 @@ extern "C" int cray_read_exr(const char* path, uint32_t* w_out, uint32_t* h_out,
     if (chans != "B,G,R,") return fail("expected channels B,G,R");
     if (x0 != 0 || y0 != 0 || x1 < 0 || y1 < 0) return fail("bad dataWindow");
     const uint32_t w = (uint32_t)x1 + 1, h = (uint32_t)y1 + 1;
+    // the file must be able to hold what the window announces: offset table + h uncompressed scan-line blocks
+    if ((uint64_t)h * (16 + (uint64_t)w * 12) > d.size() - p) return fail("dataWindow larger than the file");
     *w_out = w; *h_out = h;
     if (!rgb) return CRAY_OK;
     if (cap < (uint64_t)w * h * 3) return fail("output buffer too small");
@@ -121,7 +126,7 @@ extern "C" int cray_read_exr(const char* path, uint32_t* w_out, uint32_t* h_out,
     if (table + (size_t)h * 8 > d.size()) return fail("truncated offset table");
     for (uint32_t i = 0; i < h; i++) {
         uint64_t off; memcpy(&off, &d[table + (size_t)i * 8], 8);
-        if (off + 8 + (uint64_t)w * 12 > d.size()) return fail("truncated scan line");
+        if (off > d.size() || (uint64_t)w * 12 + 8 > d.size() - off) return fail("truncated scan line");   // no wrap-around
         const int32_t y = rd_i32(off), nbytes = rd_i32(off + 4);
         if (y < 0 || (uint32_t)y >= h || (uint64_t)nbytes != (uint64_t)w * 12) return fail("bad scan line block");
         const uint8_t* src = &d[off + 8];

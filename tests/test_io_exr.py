@@ -74,3 +74,34 @@ def test_errors():
         backend.write_exr('/nonexistent-dir/x.exr', np.zeros((2, 2, 3), dtype=np.float32))
     with pytest.raises(backend.CrayError):
         backend.read_exr('/nonexistent-dir/x.exr')
+
+
+def test_damaged_files_are_errors_not_crashes(tmp_path):
+    """Truncated and corrupted files (header, channel list, offset table, scan lines) come back as CrayError: every read of
+    cray_read_exr is bounded by the file size."""
+    path = str(tmp_path / 'a.exr')
+    rng = np.random.default_rng(3)
+    backend.write_exr(path, rng.standard_normal((5, 7, 3)).astype(np.float32))
+    data = open(path, 'rb').read()
+    bad = str(tmp_path / 'bad.exr')
+    for cut in list(range(0, 120, 3)) + list(range(len(data) - 100, len(data), 7)):
+        open(bad, 'wb').write(data[:cut])
+        with pytest.raises(backend.CrayError):
+            backend.read_exr(bad)
+    for _ in range(300):
+        b = bytearray(data)
+        for _ in range(int(rng.integers(1, 5))):
+            b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        open(bad, 'wb').write(bytes(b))
+        try:
+            img = backend.read_exr(bad)
+            assert img.shape[2] == 3
+        except backend.CrayError:
+            pass
+    # a channel list without its terminators, and a scan-line offset that would wrap around
+    i = data.index(b'channels\0chlist\0') + 16
+    b = bytearray(data)
+    b[i + 4:i + 4 + 200] = b'B' * 200
+    open(bad, 'wb').write(bytes(b))
+    with pytest.raises(backend.CrayError):
+        backend.read_exr(bad)
