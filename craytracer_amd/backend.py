@@ -22,7 +22,8 @@ class RenderParams(C.Structure):
     _fields_ = [('seed', C.c_uint64), ('tile_width', C.c_uint32), ('tile_height', C.c_uint32),
                 ('sample_batch', C.c_uint32), ('rank', C.c_uint32), ('world_size', C.c_uint32),
                 ('sample_begin', C.c_uint32), ('sample_end', C.c_uint32), ('out_is_device', C.c_uint32),
-                ('count_traversal', C.c_uint32), ('max_paths_in_flight', C.c_uint64)]
+                ('count_traversal', C.c_uint32), ('max_paths_in_flight', C.c_uint64),
+                ('integrator', C.c_uint32), ('sampler', C.c_uint32), ('uniform_nx', C.c_uint32), ('uniform_ny', C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -350,9 +351,17 @@ class DeviceScene:
         self.width, self.height, self.num_samples, self.max_depth = w.value, h.value, ns.value, depth.value
         self.device_bytes = lib().cray_scene_device_bytes(self._h)
 
+    #: selectable alternatives of the reference, applied to every later render of this DeviceScene:
+    #: integrator 'path' | 'simple' (src/simple_integrator.rs), uniform_sampler None | (nx, ny) (sampling.rs:154-194)
+    integrator = 'path'
+    uniform_sampler = None
+
     def params(self, seed=0, rank=0, world_size=1, sample_range=None, count_traversal=False, max_paths_in_flight=0):
         p = RenderParams()
         lib().cray_render_params_default(C.byref(p))
+        p.integrator = {'path': 0, 'simple': 1}[self.integrator]
+        if self.uniform_sampler is not None:
+            p.sampler, (p.uniform_nx, p.uniform_ny) = 1, self.uniform_sampler
         p.seed, p.rank, p.world_size = seed, rank, world_size
         if sample_range is not None:
             p.sample_begin, p.sample_end = sample_range

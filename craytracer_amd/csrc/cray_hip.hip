@@ -647,15 +647,21 @@ std::vector<uint32_t> rank_pixels(uint32_t W, uint32_t H, const cray_render_para
 template <int I>
 struct ShadeLaunch {
     template <class... A>
-    static void go(int variant, dim3 grid, hipStream_t st, A... args) {
-        if (variant == I) hipLaunchKernelGGL((k_shade<kShadeVariants[I]>), grid, dim3(kBlock), 0, st, args...);
-        else ShadeLaunch<I + 1>::go(variant, grid, st, args...);
+    static void go(int variant, int mode, dim3 grid, hipStream_t st, A... args) {
+        if (mode != 0) {  // the selectable alternatives of the reference (simple integrator, uniform sampler): all-features kernel
+            if (mode == kModeSimple) hipLaunchKernelGGL((k_shade<SF_ALL, kModeSimple>), grid, dim3(kBlock), 0, st, args...);
+            else if (mode == kModeUniform) hipLaunchKernelGGL((k_shade<SF_ALL, kModeUniform>), grid, dim3(kBlock), 0, st, args...);
+            else hipLaunchKernelGGL((k_shade<SF_ALL, kModeSimple | kModeUniform>), grid, dim3(kBlock), 0, st, args...);
+            return;
+        }
+        if (variant == I) hipLaunchKernelGGL((k_shade<kShadeVariants[I], 0>), grid, dim3(kBlock), 0, st, args...);
+        else ShadeLaunch<I + 1>::go(variant, mode, grid, st, args...);
     }
 };
 template <>
 struct ShadeLaunch<kNumShadeVariants> {
     template <class... A>
-    static void go(int, dim3, hipStream_t, A...) {}
+    static void go(int, int, dim3, hipStream_t, A...) {}
 };
 
 int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const PassPlan& pp, EventTimer* tm) {
@@ -667,7 +673,9 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
     const bool count = prm.count_traversal != 0;
 
     if (tm) { int e = tm->begin(FAM_OTHER); if (e) return e; }
-    hipLaunchKernelGGL(k_raygen, dim3(grid_for(c, n_paths, 8)), dim3(kBlock), 0, st, d, c->ps, c->pix_list, pp.px0, n_paths, spp_pass, pp.s_lo, prm.seed);
+    const uint32_t uni_nx = prm.sampler == CRAY_SAMPLER_UNIFORM ? prm.uniform_nx : 0u, uni_ny = prm.sampler == CRAY_SAMPLER_UNIFORM ? prm.uniform_ny : 0u;
+    const int mode = (prm.integrator == CRAY_INTEGRATOR_SIMPLE ? kModeSimple : 0) | (uni_nx ? kModeUniform : 0);
+    hipLaunchKernelGGL(k_raygen, dim3(grid_for(c, n_paths, 8)), dim3(kBlock), 0, st, d, c->ps, c->pix_list, pp.px0, n_paths, spp_pass, pp.s_lo, prm.seed, uni_nx, uni_ny);
     if (tm) { int e = tm->end(); if (e) return e; }
 
     // Launch sequence of a pass.  The shadow rays of bounce b and the path segments of bounce b+1 both depend on
@@ -700,11 +708,11 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
         if (c->sort_shade) {
             hipLaunchKernelGGL(k_classify, dim3(grid_for(c, n_paths, 8)), dim3(kBlock), 0, st, d, c->ps, q, nq, n_paths, c->class_queues, c->capacity, ctr->n_class);
             for (int cl = 0; cl < kShadeClasses; cl++)
-                ShadeLaunch<0>::go(s->shade_variant, dim3(g_shade), st, d, c->ps, (const uint32_t*)(c->class_queues + (size_t)cl * c->capacity),
-                                   (const unsigned int*)&ctr->n_class[cl], 0u, b, spp_pass, pp.s_lo, q_next, n_next, c->shadow_queue, &ctr->n_shadow, ctr, trace_all);
+                ShadeLaunch<0>::go(s->shade_variant, mode, dim3(g_shade), st, d, c->ps, (const uint32_t*)(c->class_queues + (size_t)cl * c->capacity),
+                                   (const unsigned int*)&ctr->n_class[cl], 0u, b, spp_pass, pp.s_lo, q_next, n_next, c->shadow_queue, &ctr->n_shadow, ctr, trace_all, uni_nx, uni_ny);
         } else {
-            ShadeLaunch<0>::go(s->shade_variant, dim3(g_shade), st, d, c->ps, q, nq, n_paths, b, spp_pass, pp.s_lo, q_next, n_next,
-                               c->shadow_queue, &ctr->n_shadow, ctr, trace_all);
+            ShadeLaunch<0>::go(s->shade_variant, mode, dim3(g_shade), st, d, c->ps, q, nq, n_paths, b, spp_pass, pp.s_lo, q_next, n_next,
+                               c->shadow_queue, &ctr->n_shadow, ctr, trace_all, uni_nx, uni_ny);
         }
         if (tm) { int e = tm->end(); if (e) return e; }
 
@@ -739,7 +747,18 @@ int check_render_args(cray_ctx* c, cray_scene* s, const cray_render_params* p) {
         set_last_error("cray_render: bad tile/batch/rank parameters");
         return CRAY_ERR_INVALID;
     }
-    if (s->dev.num_samples > 65536) { set_last_error("sobol_burley indexes at most 2^16 samples"); return CRAY_ERR_UNSUPPORTED; }
+    if (p->integrator > CRAY_INTEGRATOR_SIMPLE || p->sampler > CRAY_SAMPLER_UNIFORM) { set_last_error("cray_render: unknown integrator / sampler"); return CRAY_ERR_INVALID; }
+    if (p->sampler == CRAY_SAMPLER_UNIFORM) {
+        // UniformSampler::num_samples() = nx * ny is what `render` divides by (craytracer.rs:235, 255): it must be the scene's
+        if (p->uniform_nx == 0 || p->uniform_ny == 0 || (uint64_t)p->uniform_nx * p->uniform_ny != s->dev.num_samples) {
+            set_last_error("cray_render: UniformSampler %u x %u does not give the scene's %u samples", p->uniform_nx, p->uniform_ny, s->dev.num_samples);
+            return CRAY_ERR_INVALID;
+        }
+    } else if (s->dev.num_samples > 65536) { set_last_error("sobol_burley indexes at most 2^16 samples"); return CRAY_ERR_UNSUPPORTED; }
+    if (p->integrator == CRAY_INTEGRATOR_SIMPLE && p->sampler == CRAY_SAMPLER_SOBOL && 4 + 7 * (uint64_t)s->dev.max_depth > 256) {
+        set_last_error("max_depth %u needs more than sobol_burley's 256 dimensions", s->dev.max_depth);
+        return CRAY_ERR_UNSUPPORTED;
+    }
     return CRAY_OK;
 }
 

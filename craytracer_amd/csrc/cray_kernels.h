@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace_mixed(DevSce
 // measured: k_film gets trivially coalesced, but the traversal and k_shade lose the coherence of the 16
 // samples of one pixel sitting in adjacent lanes: +13 ms closest, +8 ms shade per frame.)
 __global__ void __launch_bounds__(kBlock) k_raygen(DevScene sc, PathState ps, const uint32_t* __restrict__ pix_list, uint32_t px0,
-                                                   uint32_t n_paths, uint32_t spp_pass, uint32_t s_lo, uint64_t seed) {
+                                                   uint32_t n_paths, uint32_t spp_pass, uint32_t s_lo, uint64_t seed, uint32_t uni_nx, uint32_t uni_ny) {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n_paths; p += stride) {
         const uint32_t pix = pix_list[px0 + p / spp_pass];
@@ -313,7 +313,12 @@ __global__ void __launch_bounds__(kBlock) k_raygen(DevScene sc, PathState ps, co
         const uint32_t x = pix % sc.film_w, y = pix / sc.film_w;
         const uint32_t h = pixel_seed(seed, x, y);  // SobolSampler::start_pixel
         double u[4];
-        sobol4(sc.sobol, s, 0, h, u);  // dims 0,1 film; 2,3 lens (always drawn, craytracer.rs:153-154)
+        if (uni_nx) {  // UniformSampler::sample_2d (sampling.rs:185-192): the centre of slot (s % nx, s / nx), for film and lens alike
+            u[0] = u[2] = ((double)(s % uni_nx) + 0.5) / (double)uni_nx;
+            u[1] = u[3] = ((double)(s / uni_nx) + 0.5) / (double)uni_ny;
+        } else {
+            sobol4(sc.sobol, s, 0, h, u);  // dims 0,1 film; 2,3 lens (always drawn, craytracer.rs:153-154)
+        }
         ray_t r = camera_ray(sc, u[0], u[1], u[2], u[3], x, y);
         ps.ox[p] = r.o.x; ps.oy[p] = r.o.y; ps.oz[p] = r.o.z;
         ps.dx[p] = r.d.x; ps.dy[p] = r.d.y; ps.dz[p] = r.d.z;
@@ -383,12 +388,19 @@ __global__ void __launch_bounds__(kBlock) k_classify(DevScene sc, PathState ps, 
 #ifndef CRAY_SHADE_WAVES
 #define CRAY_SHADE_WAVES 2
 #endif
-template <uint32_t F>
+// MODE bit 0: simple_integrator::estimate_Li (src/simple_integrator.rs:36-143: no MIS, no roulette, seven samples per segment)
+//      bit 1: UniformSampler (src/sampling.rs:154-194) instead of SobolSampler; uni_nx / uni_ny are its two slot counts.
+// The reference's `main` runs mode 0 (path integrator + Sobol, craytracer.rs:159-160, 361); the others are its selectable
+// alternatives and run on the all-features instantiation only.
+enum { kModeSimple = 1, kModeUniform = 2 };
+template <uint32_t F, int MODE = 0>
 __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
                                                   const unsigned int* __restrict__ n_ptr, uint32_t n_fixed, uint32_t bounce,
                                                   uint32_t spp_pass, uint32_t s_lo, uint32_t* __restrict__ next_queue,
                                                   unsigned int* next_count, uint32_t* __restrict__ shadow_queue,
-                                                  unsigned int* shadow_count, Counters* ctr, uint32_t trace_all_shadow) {
+                                                  unsigned int* shadow_count, Counters* ctr, uint32_t trace_all_shadow,
+                                                  uint32_t uni_nx, uint32_t uni_ny) {
+    constexpr bool kSimple = (MODE & kModeSimple) != 0, kUniform = (MODE & kModeUniform) != 0;
     const uint32_t n = n_ptr ? *n_ptr : n_fixed;
     // Queue appends are aggregated per block over a tile of kShadeTile paths: survivors are collected
     // in LDS (wave ballot + one LDS atomic per wave) and flushed with ONE global atomic per queue and
@@ -436,7 +448,7 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
                     rgb Le = mkc(l.c[0], l.c[1], l.c[2]);
                     if (specular_bounce) {
                         add_L(beta * Le);  // :64-67
-                    } else if (!black(Le)) {  // :68-88; pdf_Li of Infinite = 1/(4 pi) (light.rs:140)
+                    } else if (!kSimple && !black(Le)) {  // :68-88; pdf_Li of Infinite = 1/(4 pi) (light.rs:140); simple_integrator.rs:57-61 adds nothing
                         double light_pdf = (kInvPi / 4.0) * light_select_pdf(sc, li);
                         double w = power_heuristic(light_pdf, prev_pdf);
                         add_L(beta * Le * w);
@@ -458,8 +470,32 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
                 const uint32_t sidx = s_lo + p % spp_pass;
                 const uint32_t h = ps.hash[p];
                 double sa[4], sb[4];
-                sobol4(sc.sobol, sidx, 1 + 2 * bounce, h, sa);  // material 1D, material 2D, light index
-                sobol4(sc.sobol, sidx, 2 + 2 * bounce, h, sb);  // light 1D, light 2D, roulette
+                if (kUniform) {  // every 1-D draw is (s + 0.5) / (nx ny), every 2-D draw the slot centre (sampling.rs:180-192)
+                    const double u1 = ((double)sidx + 0.5) / (double)(uni_nx * uni_ny);
+                    const double ux = ((double)(sidx % uni_nx) + 0.5) / (double)uni_nx, uy = ((double)(sidx / uni_nx) + 0.5) / (double)uni_ny;
+                    sa[0] = u1; sa[1] = ux; sa[2] = uy; sa[3] = u1;
+                    sb[0] = u1; sb[1] = ux; sb[2] = uy; sb[3] = u1;
+                } else if (kSimple) {  // seven draws per segment: dimensions 4 + 7 b .. 10 + 7 b straddle the 4-D sets
+                    const uint32_t first = 4 + 7 * bounce, off = first & 3;   // uniform over the launch
+                    double flat[12];                                         // the (at most) three 4-D sets the seven draws touch
+                    sobol4(sc.sobol, sidx, (first >> 2), h, flat);
+                    sobol4(sc.sobol, sidx, (first >> 2) + 1, h, flat + 4);
+                    if (off + 7 > 8) sobol4(sc.sobol, sidx, (first >> 2) + 2, h, flat + 8);
+                    else { flat[8] = flat[9] = flat[10] = flat[11] = 0.0; }
+                    double v7[7];
+#pragma unroll
+                    for (uint32_t j = 0; j < 7; j++) {
+                        double pick = flat[j];
+#pragma unroll
+                        for (uint32_t o = 1; o < 4; o++) pick = off == o ? flat[j + o] : pick;
+                        v7[j] = pick;
+                    }
+                    sa[0] = v7[0]; sa[1] = v7[1]; sa[2] = v7[2]; sa[3] = v7[3];
+                    sb[0] = v7[4]; sb[1] = v7[5]; sb[2] = v7[6]; sb[3] = 0.0;
+                } else {
+                    sobol4(sc.sobol, sidx, 1 + 2 * bounce, h, sa);  // material 1D, material 2D, light index
+                    sobol4(sc.sobol, sidx, 2 + 2 * bounce, h, sb);  // light 1D, light 2D, roulette
+                }
 
                 // emission at the hit (:106-126)
                 if (pr.light >= 0) {
@@ -469,7 +505,7 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
                         specular_bounce = bounce == 0 || (ps.flags[p] & 1u) != 0;  // camera rays count as specular (:50)
                         if (specular_bounce) {
                             add_L(beta * Le);
-                        } else {
+                        } else if (!kSimple) {  // simple_integrator.rs:84-86 has no MIS branch
                             double lp = light_shape_pdf_from<F>(sc, l, x, n_s, w_o);
                             double light_pdf = lp * light_select_pdf(sc, (uint32_t)sc.first_equal_light[pr.light]);
                             prev_pdf = ps.prev_pdf[p];  // bounce > 0 here
@@ -484,7 +520,7 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
                 // A material without a diffuse lobe makes the gated term exactly zero: the light is not even
                 // sampled (unless traversal is being counted).  Deviation from the reference only where it
                 // would panic anyway: a non-finite Li / pdf factor times that zero (NaN) on an unoccluded ray.
-                if (!trace_all_shadow && !material_has_diffuse_lobe(sc, mat)) {
+                if (!kSimple && !trace_all_shadow && !material_has_diffuse_lobe(sc, mat)) {
                     skip_shadow = true;
                 } else {
                     double sel_pdf;
@@ -522,7 +558,14 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
                     rgb f = material_f<F>(sc, mat, w_o, w_i, n_s, sp.u, sp.v);
                     double cos_t = fabs(dot(w_i, n_s));
                     rgb contrib = mkc(0, 0, 0);
-                    if (!delta) {
+                    bool queried = true;  // does the reference call Scene::intersects for this segment at all?
+                    if (kSimple) {
+                        // simple_integrator.rs:102-111: Delta -> 1.0; the shadow ray is only cast when light_pdf > 0
+                        // (`&&` short-circuit) and the term is beta * Li * f * cos / p_select / light_pdf, no MIS weight
+                        const double light_pdf = delta ? 1.0 : lpdf;
+                        queried = light_pdf > 0.0;
+                        if (queried) contrib = beta * Li * f * cos_t / sel_pdf / light_pdf;
+                    } else if (!delta) {
                         if (lpdf > 0.0) {
                             double light_pdf = lpdf * sel_pdf;
                             double bsdf_pdf = 0.0;
@@ -536,8 +579,8 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
                     // The reference queries Scene::intersects unconditionally (:141).  When the term it
                     // gates is exactly zero (pdf 0, black f, light behind the surface) the answer cannot
                     // change L (L + 0 == L), so the query is skipped unless traversal is being counted.
-                    want_shadow = trace_all_shadow || !black(contrib);
-                    skip_shadow = !want_shadow;
+                    want_shadow = queried && (trace_all_shadow || !black(contrib));
+                    skip_shadow = queried && !want_shadow;
                     if (want_shadow) {
                         ps.sox[p] = x.x; ps.soy[p] = x.y; ps.soz[p] = x.z;
                         ps.sdx[p] = w_i.x; ps.sdy[p] = w_i.y; ps.sdz[p] = w_i.z;
@@ -566,7 +609,7 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
                 if (go) {
                     double cos_t = fabs(dot(ls.w_i, n_s));
                     beta = beta * ls.f * cos_t / bsdf_pdf;
-                    if (bounce > 0) {
+                    if (bounce > 0 && !kSimple) {  // Russian roulette: path integrator only (path_integrator.rs:197-206)
                         double m = max_nn(beta.r, max_nn(beta.g, beta.b));
                         if (m < 1.0) {
                             double q = 1.0 - m;

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CRAY_ABI_VERSION 1
+#define CRAY_ABI_VERSION 2
 
 enum {
     CRAY_OK = 0,
@@ -102,7 +102,16 @@ typedef struct {
     uint32_t count_traversal;   /* 1: also count BVH nodes / primitive tests (cray_stats) of EVERY query the reference
                                    makes; 2: count only the queries actually traversed (zero-term shadow rays skipped) */
     uint64_t max_paths_in_flight; /* 0 = default */
+    /* The reference's selectable alternatives (ABI 2).  `main` hard-wires the path integrator with the Sobol sampler
+     * (craytracer.rs:159-160, 361); simple_integrator::estimate_Li (src/simple_integrator.rs:36-143: no MIS, no roulette)
+     * and UniformSampler (src/sampling.rs:154-194: slot centres, uniform_nx * uniform_ny must equal Scene.num_samples) are
+     * what a maintainer gets by editing those lines.  IndependentSampler (rand's ChaCha12 StdRng) is not provided. */
+    uint32_t integrator;        /* CRAY_INTEGRATOR_PATH (default) | CRAY_INTEGRATOR_SIMPLE */
+    uint32_t sampler;           /* CRAY_SAMPLER_SOBOL (default) | CRAY_SAMPLER_UNIFORM */
+    uint32_t uniform_nx, uniform_ny;
 } cray_render_params;
+enum { CRAY_INTEGRATOR_PATH = 0, CRAY_INTEGRATOR_SIMPLE = 1 };
+enum { CRAY_SAMPLER_SOBOL = 0, CRAY_SAMPLER_UNIFORM = 1 };
 
 typedef struct {
     uint64_t paths;                         /* W*H*spp rendered by this call */

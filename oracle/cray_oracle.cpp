@@ -164,7 +164,14 @@ static inline float sobol_sample(uint32_t sample_index, uint32_t dimension, uint
     return v[dimension & 3];
 }
 
-/* SobolSampler, src/sampling.rs:196-247 */
+/* Which of the reference's samplers / integrators the oracle runs (orc_set_mode): `main` uses SobolSampler + the path
+ * integrator (craytracer.rs:159-160, 361); UniformSampler (sampling.rs:154-194) and simple_integrator::estimate_Li
+ * (simple_integrator.rs:36-143) are its selectable alternatives. */
+static int g_integrator = 0;                 /* 0 path_integrator, 1 simple_integrator */
+static int g_sampler_kind = 0;               /* 0 Sobol, 1 Uniform */
+static uint64_t g_uniform_nx = 1, g_uniform_ny = 1;
+
+/* SobolSampler, src/sampling.rs:196-247; UniformSampler, :154-194 */
 struct Sampler {
     uint64_t seed;
     uint32_t hash, sample_index, dimension;
@@ -174,11 +181,19 @@ struct Sampler {
         dimension = 0;
     }
     double sample_1d() { /* :234-238 */
+        if (g_sampler_kind == 1) /* :180-183 */
+            return ((double)sample_index + 0.5) / (double)(g_uniform_nx * g_uniform_ny);
         float s = sobol_sample(sample_index, dimension, hash);
         dimension += 1;
         return (double)s;
     }
     void sample_2d(double* a, double* b) { /* :240-246 */
+        if (g_sampler_kind == 1) { /* :185-192 */
+            uint64_t x = sample_index % g_uniform_nx, y = sample_index / g_uniform_nx;
+            *a = ((double)x + 0.5) / (double)g_uniform_nx;
+            *b = ((double)y + 0.5) / (double)g_uniform_ny;
+            return;
+        }
         float sx = sobol_sample(sample_index, dimension, hash);
         dimension += 1;
         float sy = sobol_sample(sample_index, dimension, hash);
@@ -1258,6 +1273,65 @@ static Col estimate_Li(const Scene& sc, Sampler& sampler, Ray ray, Stats* st, do
     return L;
 }
 
+/* simple_integrator::estimate_Li, src/simple_integrator.rs:36-143: direct lighting by one light sample per segment, no
+ * multiple importance sampling, no Russian roulette; seven samples per segment (:26-32, struct-literal field order). */
+static Col estimate_Li_simple(const Scene& sc, Sampler& sampler, Ray ray, Stats* st) {
+    Col L = BLACK, beta = WHITE;
+    uint32_t bounces = 0;
+    bool is_specular_bounce = true;
+    int af = 0;
+    while (bounces < sc.max_depth && !is_black(beta)) {
+        V3 w_o = neg(ray.d);
+        Hit isect;
+        if (!bvh_intersect(sc, ray, &isect, st)) {
+            if (is_specular_bounce) /* :57-61 */
+                for (size_t i = 0; i < sc.lights.size(); i++) L = L + beta * light_Le(sc.lights[i]);
+            break;
+        }
+        V3 normal = isect.normal, location = isect.location;
+        double tu = isect.u, tv = isect.v;
+        const cray_prim& prim = sc.prims[isect.prim];
+        int material = prim.light >= 0 ? MATERIAL_AREA_LIGHT : prim.material;
+
+        double m1 = sampler.sample_1d();
+        double m2a, m2b; sampler.sample_2d(&m2a, &m2b);
+        double li_idx = sampler.sample_1d();
+        double l1 = sampler.sample_1d();
+        double l2a, l2b; sampler.sample_2d(&l2a, &l2b);
+
+        if (is_specular_bounce && prim.light >= 0) L = L + beta * sc.lights[prim.light].c; /* :84-86, PrimitiveIntersection::Le */
+
+        { /* :89-112 */
+            double light_sampler_pdf_v;
+            size_t light_index = light_sampler_sample(sc, li_idx, &light_sampler_pdf_v);
+            const Light& light = sc.lights[light_index];
+            LightSample ls = light_sample_Li(sc, light, l1, l2a, l2b, location, normal);
+            double light_pdf = ls.delta ? 1.0 : ls.pdf;
+            if (light_pdf > 0.0 && !bvh_intersects(sc, ls.shadow_ray, st)) {
+                Col f = material_f(sc, material, w_o, ls.w_i, normal, tu, tv);
+                double cos_theta = std::fabs(dot(ls.w_i, normal));
+                L = L + beta * ls.Li * f * cos_theta / light_sampler_pdf_v / light_pdf;
+            }
+        }
+        { /* :115-137 */
+            SurfaceSample ss;
+            if (!material_sample(sc, material, m1, m2a, m2b, w_o, normal, tu, tv, &ss, &af)) break;
+            if (is_black(ss.f)) break;
+            double cos_theta = std::fabs(dot(ss.w_i, normal));
+            double bsdf_pdf = ss.delta ? 1.0 : ss.pdf;
+            if (bsdf_pdf == 0.0) break;
+            beta = beta * ss.f * cos_theta / bsdf_pdf;
+            ray = ray_new(location, ss.w_i);
+            is_specular_bounce = ss.is_specular;
+        }
+        if (!is_finite(L) || !is_finite(beta)) st->nonfinite += 1; /* :139-140 */
+        bounces += 1;
+    }
+    st->assert_fail += (uint64_t)af;
+    st->paths += 1;
+    return L;
+}
+
 /* render_pixel, src/bin/craytracer.rs:148-162 */
 static Col render_pixel(const Scene& sc, Sampler& sampler, uint64_t x, uint64_t y, uint64_t s, Stats* st) {
     sampler.start_pixel(x, y, s);
@@ -1265,7 +1339,7 @@ static Col render_pixel(const Scene& sc, Sampler& sampler, uint64_t x, uint64_t 
     sampler.sample_2d(&fx, &fy);
     sampler.sample_2d(&lx, &ly);
     Ray ray = camera_sample(sc, fx, fy, lx, ly, x, y);
-    return estimate_Li(sc, sampler, ray, st);
+    return g_integrator == 1 ? estimate_Li_simple(sc, sampler, ray, st) : estimate_Li(sc, sampler, ray, st);
 }
 
 /* ======================================================================== */
@@ -1521,6 +1595,11 @@ void orc_camera_ray(void* s, uint64_t seed, uint32_t x, uint32_t y, uint32_t sam
 
 /* 0: correctly rounded sin/cos in the sampling functions (default); 1: platform libm */
 void orc_set_libm_mode(int mode) { g_libm_mode = mode; }
+/* integrator: 0 path, 1 simple; sampler: 0 Sobol, 1 Uniform(nx, ny) */
+void orc_set_mode(int integrator, int sampler, uint64_t nx, uint64_t ny) {
+    g_integrator = integrator; g_sampler_kind = sampler;
+    g_uniform_nx = nx ? nx : 1; g_uniform_ny = ny ? ny : 1;
+}
 /* 64 x 16 x 4 bit-reversed direction vectors (sobol_burley's REV_VECTORS layout); NULL restores the built-in table */
 void orc_set_sobol_vectors(const uint16_t* v) {
     if (!v) { g_sobol_table = CRAY_SOBOL_REV_VECTORS; return; }

@@ -90,6 +90,7 @@ def lib():
         L.orc_partition_by.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int64, C.c_int64]
         L.orc_set_libm_mode.argtypes = [C.c_int]
         L.orc_set_sobol_vectors.argtypes = [C.c_void_p]
+        L.orc_set_mode.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint64]
         L.orc_sample_sin.restype = C.c_double
         L.orc_sample_sin.argtypes = [C.c_double]
         L.orc_sample_cos.restype = C.c_double
@@ -102,6 +103,13 @@ def lib():
 def set_libm_mode(mode):
     """0: correctly rounded sin/cos in the sampling functions (default); 1: platform libm."""
     lib().orc_set_libm_mode(mode)
+
+
+def set_mode(integrator='path', uniform_sampler=None):
+    """Which of the reference's integrators / samplers the oracle runs: 'path' (main's) or 'simple'
+    (src/simple_integrator.rs); uniform_sampler = (nx, ny) selects UniformSampler (sampling.rs:154-194), None the Sobol sampler."""
+    nx, ny = uniform_sampler if uniform_sampler is not None else (0, 0)
+    lib().orc_set_mode({'path': 0, 'simple': 1}[integrator], 1 if uniform_sampler is not None else 0, nx, ny)
 
 
 def set_sobol_vectors(table):
