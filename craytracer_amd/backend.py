@@ -64,7 +64,8 @@ class FlatScene(C.Structure):
                 ('n_images', C.c_uint32), ('images', C.c_void_p),
                 ('image_pool_bytes', C.c_uint64), ('image_pool', C.c_void_p),
                 ('n_lights', C.c_uint32), ('lights', C.c_void_p),
-                ('light_cdf', C.c_void_p), ('first_equal_light', C.c_void_p)]
+                ('light_cdf', C.c_void_p), ('first_equal_light', C.c_void_p),
+                ('build_on_device', C.c_uint32), ('n_other_bounds', C.c_uint32), ('other_bounds', C.c_void_p)]
 
 
 #: every symbol include/cray.h and include/cray_host.h declare
@@ -83,7 +84,8 @@ ABI_SYMBOLS = ['cray_ctx_create', 'cray_ctx_destroy', 'cray_scene_upload', 'cray
                'cray_cry_parse_scene', 'cray_owned_scene_desc', 'cray_owned_scene_warnings', 'cray_owned_scene_free',
                'cray_scene_info', 'cray_comm_unique_id', 'cray_comm_init', 'cray_comm_rank', 'cray_comm_world_size',
                'cray_comm_barrier', 'cray_comm_allreduce_f64', 'cray_scene_broadcast', 'cray_render_gather',
-               'cray_film_gather', 'cray_film_pack', 'cray_film_unpack', 'cray_measure_stream_read', 'cray_load_image', 'cray_free_image', 'cray_default_image_loader', 'cray_set_sobol_vectors']
+               'cray_film_gather', 'cray_film_pack', 'cray_film_unpack', 'cray_measure_stream_read', 'cray_load_image', 'cray_free_image', 'cray_default_image_loader', 'cray_set_sobol_vectors',
+               'cray_host_scene_new_resident', 'cray_scene_build_stats']
 
 _lib = None
 #: how the loaded library came to be: 'shipped' (the .so in the tree was current), 'rebuilt' (sources were newer, hipcc ran),
@@ -132,6 +134,9 @@ def lib():
     L.cray_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.POINTER(Stats)]
     L.cray_host_scene_new.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
     L.cray_host_scene_new_on.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.cray_host_scene_new_resident.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    L.cray_scene_build_stats.restype = None
+    L.cray_scene_build_stats.argtypes = [C.c_void_p, C.POINTER(BvhBuildStats)]
     L.cray_host_scene_bvh_seconds.restype = C.c_double
     L.cray_host_scene_bvh_seconds.argtypes = [C.c_void_p, C.POINTER(BvhBuildStats)]
     L.cray_bvh_build_sah.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32),
@@ -181,11 +186,15 @@ class HostScene:
 
     SAH, MEDIAN = 1, 0
 
-    def __init__(self, scene, split_method=1, bvh_ctx=None):
-        """bvh_ctx: a Context whose GPU runs Bvh::new (cray_bvh_build_sah, same tree); None = host build."""
+    def __init__(self, scene, split_method=1, bvh_ctx=None, resident=False):
+        """bvh_ctx: a Context whose GPU runs Bvh::new (cray_bvh_build_sah, same tree); None = host build.
+        resident=True: no tree here at all — Context.upload builds it on the GPU and keeps it there (the fastest path from a
+        description to a renderable scene; bvh() is then unavailable)."""
         self.scene = scene  # keeps the description arrays alive (the flat view borrows them)
         h = C.c_void_p()
-        if bvh_ctx is None:
+        if resident:
+            _check(lib().cray_host_scene_new_resident(C.addressof(scene.desc()), C.byref(h)), 'cray_host_scene_new_resident')
+        elif bvh_ctx is None:
             _check(lib().cray_host_scene_new(C.addressof(scene.desc()), split_method, C.byref(h)), 'cray_host_scene_new')
         else:
             _check(lib().cray_host_scene_new_on(C.addressof(scene.desc()), split_method, bvh_ctx._h, C.byref(h)),
@@ -350,6 +359,9 @@ class DeviceScene:
         lib().cray_scene_info(self._h, C.byref(w), C.byref(h), C.byref(ns), C.byref(depth))
         self.width, self.height, self.num_samples, self.max_depth = w.value, h.value, ns.value, depth.value
         self.device_bytes = lib().cray_scene_device_bytes(self._h)
+        g = BvhBuildStats()
+        lib().cray_scene_build_stats(self._h, C.byref(g))
+        self.build_stats = {k: getattr(g, k) for k, _ in BvhBuildStats._fields_}   # resident build: Bvh::new inside the upload
 
     #: selectable alternatives of the reference, applied to every later render of this DeviceScene:
     #: integrator 'path' | 'simple' (src/simple_integrator.rs), uniform_sampler None | (nx, ny) (sampling.rs:154-194)

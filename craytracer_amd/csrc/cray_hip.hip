@@ -105,6 +105,7 @@ struct cray_scene {
     std::vector<size_t> alloc_bytes;  // parallel to allocs, in the order of scene_arrays()
     uint64_t bytes = 0;
     uint32_t n_prims = 0;
+    cray_bvh_build_stats build_stats{};  // resident build only
     uint32_t features = SF_ALL;  // what the scene can make k_shade do (cray_shading.h)
     int shade_variant = kNumShadeVariants - 1;
 };
@@ -245,6 +246,25 @@ extern "C" const char* cray_last_error(void) { return g_err; }
 
 static void comm_release(cray_ctx* c);  // cray_comm section at the end of this file
 
+namespace {
+struct DevMem {  // frees its allocations on every exit path
+    std::vector<void*> ptrs;
+    ~DevMem() { for (void* p : ptrs) (void)hipFree(p); }
+    template <class T> hipError_t get(T** out, size_t count) {
+        void* d = nullptr;
+        hipError_t e = hipMalloc(&d, (count ? count : 1) * sizeof(T));
+        if (e == hipSuccess) ptrs.push_back(d);
+        *out = (T*)d;
+        return e;
+    }
+    void release(void* p) {  // hand an allocation over to another owner
+        for (auto& q : ptrs) if (q == p) { q = ptrs.back(); ptrs.pop_back(); return; }
+    }
+};
+struct BvhOnDevice { cray_bvh_node* d_nodes; uint32_t* d_order; uint32_t n_nodes; cray_bvh_build_stats stats; };
+int bvh_build_device(cray_ctx* c, const double* d_box, uint32_t n, DevMem& mem, BvhOnDevice* r);
+}  // namespace
+
 extern "C" int cray_ctx_create(int device_id, void* stream, cray_ctx** out) {
     if (!out) { set_last_error("cray_ctx_create: out is null"); return CRAY_ERR_INVALID; }
     *out = nullptr;
@@ -303,6 +323,11 @@ extern "C" void cray_scene_free(cray_scene* s) {
     delete s;
 }
 extern "C" uint64_t cray_scene_device_bytes(const cray_scene* s) { return s ? s->bytes : 0; }
+extern "C" void cray_scene_build_stats(const cray_scene* s, cray_bvh_build_stats* out) {
+    if (!out) return;
+    memset(out, 0, sizeof(*out));
+    if (s) *out = s->build_stats;
+}
 extern "C" void cray_scene_info(const cray_scene* s, uint32_t* w, uint32_t* h, uint32_t* ns, uint32_t* depth) {
     if (!s) return;
     if (w) *w = s->dev.film_w;
@@ -330,12 +355,178 @@ static int pick_shade_variant(uint32_t features) {
     return best;
 }
 
+// ---- resident build: Bvh::new on the device and the traversal layout derived from its output in place -------------
+namespace {
+
+// Shape::bounds of a triangle (shape.rs:402-438 via Bounds::new of the three vertices): min / max of v0, v0 + e1, v0 + e2 in the
+// host's operand order (cray_host.cpp); other shapes get their host-computed box scattered in afterwards.
+__global__ void __launch_bounds__(kBlock) k_prim_bounds(const cray_prim* __restrict__ prims, const cray_triangle* __restrict__ tris, uint32_t n, uint32_t n_tris,
+                                                        double* __restrict__ box, unsigned int* __restrict__ err) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const cray_prim p = prims[i];
+    double* o = box + (size_t)i * 6;
+    if (p.shape_kind != CRAY_SHAPE_TRIANGLE) { for (int k = 0; k < 6; k++) o[k] = 0.0; return; }
+    if (p.shape >= n_tris) { atomicOr(err, 1u); return; }
+    const cray_triangle t = tris[p.shape];
+    const double v0[3] = {t.v0.x, t.v0.y, t.v0.z};
+    const double v1[3] = {t.v0.x + t.e1.x, t.v0.y + t.e1.y, t.v0.z + t.e1.z}, v2[3] = {t.v0.x + t.e2.x, t.v0.y + t.e2.y, t.v0.z + t.e2.z};
+    bool finite = true;
+    for (int k = 0; k < 3; k++) {
+        o[k] = min_nn(v1[k], min_nn(v2[k], v0[k]));
+        o[3 + k] = max_nn(v1[k], max_nn(v2[k], v0[k]));
+        finite = finite && isfinite(o[k]) && isfinite(o[3 + k]);
+    }
+    if (!finite) atomicOr(err, 2u);
+}
+__global__ void __launch_bounds__(kBlock) k_other_bounds(const cray_prim_bound* __restrict__ ob, uint32_t n_other, uint32_t n, double* __restrict__ box, unsigned int* __restrict__ err) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_other) return;
+    const cray_prim_bound b = ob[i];
+    if (b.prim >= n) { atomicOr(err, 4u); return; }
+    double* o = box + (size_t)b.prim * 6;
+    for (int k = 0; k < 3; k++) { o[k] = b.bmin[k]; o[3 + k] = b.bmax[k]; }
+}
+__global__ void __launch_bounds__(kBlock) k_flag_interior(const cray_bvh_node* __restrict__ nodes, uint32_t n_nodes, uint8_t* __restrict__ flag) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n_nodes) flag[i] = nodes[i].is_leaf ? 0 : 1;
+}
+// one 128-B record per interior node, at its rank among the interior nodes in DFS pre-order (T = exclusive scan of the flags)
+__global__ void __launch_bounds__(kBlock) k_make_inner(const cray_bvh_node* __restrict__ nodes, const uint32_t* __restrict__ T, uint32_t n_nodes,
+                                                       InnerNode* __restrict__ inner, unsigned int* __restrict__ err, unsigned int* __restrict__ out_of_div_range) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_nodes) return;
+    const cray_bvh_node nd = nodes[i];
+    bool in_range = true;
+    for (int k = 0; k < 3; k++) in_range = in_range && div_range_ok(nd.bmin[k]) && div_range_ok(nd.bmax[k]);
+    if (!in_range) atomicOr(out_of_div_range, 1u);
+    if (nd.is_leaf) { if (nd.count < 1 || nd.count > 8) atomicOr(err, 8u); return; }
+    if (nd.left >= n_nodes || nd.right >= n_nodes || nd.axis < 0 || nd.axis > 2) { atomicOr(err, 16u); return; }
+    const cray_bvh_node l = nodes[nd.left], r = nodes[nd.right];
+    InnerNode o;
+    for (int k = 0; k < 3; k++) { o.lo0[k] = l.bmin[k]; o.hi0[k] = l.bmax[k]; o.lo1[k] = r.bmin[k]; o.hi1[k] = r.bmax[k]; }
+    o.ref0 = l.is_leaf ? (kLeafBit | (l.first << 3) | (l.count - 1)) : T[nd.left];
+    o.ref1 = r.is_leaf ? (kLeafBit | (r.first << 3) | (r.count - 1)) : T[nd.right];
+    o.axis = (uint32_t)nd.axis; o.pad_ = 0; o.pad2_[0] = 0.0; o.pad2_[1] = 0.0;
+    inner[T[i]] = o;
+}
+__global__ void __launch_bounds__(kBlock) k_make_slots(const uint32_t* __restrict__ order, const cray_prim* __restrict__ prims, const cray_triangle* __restrict__ tris,
+                                                       uint32_t n, LeafSlot* __restrict__ slots) {
+    const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+    if (j > n) return;
+    LeafSlot s;
+    for (int k = 0; k < 3; k++) { s.v0[k] = 0.0; s.e1[k] = 0.0; s.e2[k] = 0.0; }
+    s.prim = 0; s.kind = 0;
+    if (j < n) {  // slot n is the zero pad the unified 112-B record fetch may read
+        const uint32_t pi = order[j];
+        const cray_prim p = prims[pi];
+        s.prim = pi; s.kind = (uint32_t)p.shape_kind;
+        if (p.shape_kind == CRAY_SHAPE_TRIANGLE) {
+            const cray_triangle t = tris[p.shape];
+            s.v0[0] = t.v0.x; s.v0[1] = t.v0.y; s.v0[2] = t.v0.z;
+            s.e1[0] = t.e1.x; s.e1[1] = t.e1.y; s.e1[2] = t.e1.z;
+            s.e2[0] = t.e2.x; s.e2[1] = t.e2.y; s.e2[2] = t.e2.z;
+        }
+    }
+    slots[j] = s;
+}
+__global__ void __launch_bounds__(kBlock) k_make_trishade(const cray_triangle* __restrict__ tris, uint32_t n_tris, TriShade* __restrict__ shade) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_tris) return;
+    const cray_triangle t = tris[i];
+    TriShade o;
+    o.n0[0] = t.n0.x; o.n0[1] = t.n0.y; o.n0[2] = t.n0.z;
+    o.n01[0] = t.n01.x; o.n01[1] = t.n01.y; o.n01[2] = t.n01.z;
+    o.n02[0] = t.n02.x; o.n02[1] = t.n02.y; o.n02[2] = t.n02.z;
+    for (int k = 0; k < 2; k++) { o.uv0[k] = t.uv0[k]; o.uv01[k] = t.uv01[k]; o.uv02[k] = t.uv02[k]; }
+    shade[i] = o;
+}
+
+// Registers the four BVH-side arrays of the scene in cray_scene_upload's order (inner, slots, prims, tri_shade).
+int build_resident(cray_ctx* c, const cray_flat_scene* f, cray_scene* s) {
+    using namespace cray::bvhb;
+    const uint32_t n = f->n_prims, n_tris = f->n_triangles;
+    if (n >= (1u << 28)) { set_last_error("too many primitives for the 28-bit leaf slot index"); return CRAY_ERR_UNSUPPORTED; }
+    hipStream_t st = c->stream;
+    DevScene& d = s->dev;
+    DevMem mem;
+    cray_triangle* d_tris; cray_prim* d_prims; double* d_box; unsigned int* d_err; cray_prim_bound* d_other;
+    HIP_TRY(mem.get(&d_tris, n_tris));
+    HIP_TRY(mem.get(&d_prims, n));
+    HIP_TRY(mem.get(&d_box, (size_t)n * 6));
+    HIP_TRY(mem.get(&d_err, 2));
+    HIP_TRY(mem.get(&d_other, f->n_other_bounds));
+    if (n_tris) HIP_TRY(hipMemcpyAsync(d_tris, f->triangles, (size_t)n_tris * sizeof(cray_triangle), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_prims, f->prims, (size_t)n * sizeof(cray_prim), hipMemcpyHostToDevice, st));
+    if (f->n_other_bounds) HIP_TRY(hipMemcpyAsync(d_other, f->other_bounds, (size_t)f->n_other_bounds * sizeof(cray_prim_bound), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(d_err, 0, 2 * sizeof(unsigned int), st));
+    const dim3 blk(kBlock), grid_n((n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_prim_bounds, grid_n, blk, 0, st, (const cray_prim*)d_prims, (const cray_triangle*)d_tris, n, n_tris, d_box, d_err);
+    if (f->n_other_bounds) hipLaunchKernelGGL(k_other_bounds, dim3((f->n_other_bounds + kBlock - 1) / kBlock), blk, 0, st, (const cray_prim_bound*)d_other, f->n_other_bounds, n, d_box, d_err);
+    unsigned int err[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(err, d_err, sizeof(err), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (err[0]) { set_last_error("resident build: bad primitive table (code %u: 1 triangle index, 2 non-finite bound, 4 other_bounds index)", err[0]); return CRAY_ERR_INVALID; }
+
+    BvhOnDevice bvh{};
+    int rc = bvh_build_device(c, d_box, n, mem, &bvh);   // Bvh::new: the reference's tree, DFS pre-order, on the device
+    if (rc != CRAY_OK) return rc;
+    const uint32_t n_nodes = bvh.n_nodes;
+
+    uint8_t* d_flag; uint32_t *d_T, *d_tile, *d_total;
+    const uint32_t n_tiles = (n_nodes + kScanTile - 1) / kScanTile;
+    HIP_TRY(mem.get(&d_flag, n_nodes));
+    HIP_TRY(mem.get(&d_T, (size_t)n_nodes + 1));
+    HIP_TRY(mem.get(&d_tile, n_tiles));
+    HIP_TRY(mem.get(&d_total, 1));
+    const dim3 grid_nodes((n_nodes + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_flag_interior, grid_nodes, blk, 0, st, (const cray_bvh_node*)bvh.d_nodes, n_nodes, d_flag);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles), dim3(kTB), 0, st, (const uint8_t*)d_flag, d_T, d_tile, n_nodes);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kTB), 0, st, d_tile, n_tiles, d_total);
+    hipLaunchKernelGGL(k_scan_add, dim3((n_nodes + kTB - 1) / kTB), dim3(kTB), 0, st, d_T, (const uint32_t*)d_tile, (const uint32_t*)d_total, n_nodes);
+    uint32_t n_inner = 0;
+    cray_bvh_node root;
+    HIP_TRY(hipMemcpyAsync(&n_inner, d_T + n_nodes, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&root, bvh.d_nodes, sizeof(root), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+
+    InnerNode* d_inner; LeafSlot* d_slots; TriShade* d_shade;
+    HIP_TRY(mem.get(&d_inner, n_inner ? n_inner : 1));
+    HIP_TRY(mem.get(&d_slots, (size_t)n + 1));
+    HIP_TRY(mem.get(&d_shade, n_tris));
+    if (!n_inner) HIP_TRY(hipMemsetAsync(d_inner, 0, sizeof(InnerNode), st));
+    hipLaunchKernelGGL(k_make_inner, grid_nodes, blk, 0, st, (const cray_bvh_node*)bvh.d_nodes, (const uint32_t*)d_T, n_nodes, d_inner, d_err, d_err + 1);
+    hipLaunchKernelGGL(k_make_slots, dim3((n + 1 + kBlock - 1) / kBlock), blk, 0, st, (const uint32_t*)bvh.d_order, (const cray_prim*)d_prims, (const cray_triangle*)d_tris, n, d_slots);
+    if (n_tris) hipLaunchKernelGGL(k_make_trishade, dim3((n_tris + kBlock - 1) / kBlock), blk, 0, st, (const cray_triangle*)d_tris, n_tris, d_shade);
+    HIP_TRY(hipMemcpyAsync(err, d_err, sizeof(err), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    if (err[0]) { set_last_error("resident build: malformed tree (code %u)", err[0]); return CRAY_ERR_INVALID; }
+
+    for (int k = 0; k < 3; k++) { d.root_lo[k] = root.bmin[k]; d.root_hi[k] = root.bmax[k]; }
+    d.root_ref = root.is_leaf ? (kLeafBit | (root.first << 3) | (root.count - 1)) : 0u;   // the root is interior record 0
+    d.n_inner = n_inner;
+    d.bounds_in_div_range = err[1] ? 0u : 1u;
+    s->build_stats = bvh.stats;
+    // hand the four arrays over to the scene, in cray_scene_upload's order
+    auto adopt = [&](void* ptr, size_t bytes) { mem.release(ptr); s->allocs.push_back(ptr); s->alloc_bytes.push_back(bytes); s->bytes += bytes; };
+    adopt(d_inner, (size_t)(n_inner ? n_inner : 1) * sizeof(InnerNode)); d.inner = d_inner;
+    adopt(d_slots, ((size_t)n + 1) * sizeof(LeafSlot)); d.slots = d_slots;
+    adopt(d_prims, (size_t)n * sizeof(cray_prim)); d.prims = d_prims;
+    adopt(d_shade, (size_t)(n_tris ? n_tris : 1) * sizeof(TriShade)); d.tri_shade = d_shade;
+    return CRAY_OK;
+}
+
+}  // namespace
+
 // Flattened reference-topology BVH -> device layout (cray_device.h).
 extern "C" int cray_scene_upload(cray_ctx* c, const cray_flat_scene* f, cray_scene** out) {
     if (!c || !f || !out) { set_last_error("cray_scene_upload: null argument"); return CRAY_ERR_INVALID; }
     *out = nullptr;
     if (f->abi_version != CRAY_ABI_VERSION) { set_last_error("flat scene abi_version %u != %u", f->abi_version, CRAY_ABI_VERSION); return CRAY_ERR_INVALID; }
-    if (f->n_nodes == 0 || f->n_prims == 0 || f->n_lights == 0) { set_last_error("scene needs nodes, primitives and lights"); return CRAY_ERR_INVALID; }
+    const bool resident = f->build_on_device != 0;   // Bvh::new runs on the GPU inside this call (build_resident below)
+    if ((!resident && f->n_nodes == 0) || f->n_prims == 0 || f->n_lights == 0) { set_last_error("scene needs nodes, primitives and lights"); return CRAY_ERR_INVALID; }
+    if (resident && (f->n_nodes != 0 || f->n_prim_refs != 0)) { set_last_error("build_on_device: the flat scene must not carry a tree"); return CRAY_ERR_INVALID; }
     if (4 + 8 * (uint64_t)f->max_depth > 256) { set_last_error("max_depth %u needs more than sobol_burley's 256 dimensions", f->max_depth); return CRAY_ERR_UNSUPPORTED; }
     if (f->n_prims >= (1u << 28)) { set_last_error("too many primitives for the 28-bit leaf slot index"); return CRAY_ERR_UNSUPPORTED; }
     HIP_TRY(hipSetDevice(c->device));
@@ -466,8 +657,11 @@ extern "C" int cray_scene_upload(cray_ctx* c, const cray_flat_scene* f, cray_sce
     d.lens_radius = f->lens_radius; d.focal_distance = f->focal_distance;
     memcpy(d.camera_from_raster, f->camera_from_raster, sizeof(d.camera_from_raster));
     memcpy(d.world_from_camera, f->world_from_camera, sizeof(d.world_from_camera));
-    for (int k = 0; k < 3; k++) { d.root_lo[k] = f->nodes[0].bmin[k]; d.root_hi[k] = f->nodes[0].bmax[k]; }
-    int e = make_ref(0, &d.root_ref);
+    int e = CRAY_OK;
+    if (!resident) {
+        for (int k = 0; k < 3; k++) { d.root_lo[k] = f->nodes[0].bmin[k]; d.root_hi[k] = f->nodes[0].bmax[k]; }
+        e = make_ref(0, &d.root_ref);
+    }
     d.n_inner = n_inner;
     d.bounds_in_div_range = 1;
     for (uint32_t i = 0; i < f->n_nodes && d.bounds_in_div_range; i++)
@@ -475,8 +669,8 @@ extern "C" int cray_scene_upload(cray_ctx* c, const cray_flat_scene* f, cray_sce
             if (!div_range_ok(f->nodes[i].bmin[k]) || !div_range_ok(f->nodes[i].bmax[k])) d.bounds_in_div_range = 0;
 
     // triangle shading records, in triangle-table order
-    std::vector<TriShade> shade(f->n_triangles);
-    for (uint32_t i = 0; i < f->n_triangles; i++) {
+    std::vector<TriShade> shade(resident ? 0 : f->n_triangles);
+    for (uint32_t i = 0; i < f->n_triangles && !resident; i++) {
         const cray_triangle& t = f->triangles[i];
         TriShade& o = shade[i];
         o.n0[0] = t.n0.x; o.n0[1] = t.n0.y; o.n0[2] = t.n0.z;
@@ -554,10 +748,14 @@ extern "C" int cray_scene_upload(cray_ctx* c, const cray_flat_scene* f, cray_sce
     double gamma_lut[256];  // Color::from_rgb (color.rs:39-46): (c/255).powf(2.2), libm pow like the reference
     for (int i = 0; i < 256; i++) gamma_lut[i] = pow((double)i / 255.0, 2.2);
 
-    if (!e) e = upload(s, inner.data(), inner.size(), &d.inner);
-    if (!e) e = upload(s, slots.data(), slots.size(), &d.slots);
-    if (!e) e = upload(s, f->prims, (size_t)f->n_prims, &d.prims);
-    if (!e) e = upload(s, shade.data(), shade.size(), &d.tri_shade);
+    if (resident) {
+        if (!e) e = build_resident(c, f, s);   // inner, slots, prims, tri_shade: built on the device, in this order
+    } else {
+        if (!e) e = upload(s, inner.data(), inner.size(), &d.inner);
+        if (!e) e = upload(s, slots.data(), slots.size(), &d.slots);
+        if (!e) e = upload(s, f->prims, (size_t)f->n_prims, &d.prims);
+        if (!e) e = upload(s, shade.data(), shade.size(), &d.tri_shade);
+    }
     if (!e) e = upload(s, f->spheres, (size_t)f->n_spheres, &d.spheres);
     if (!e) e = upload(s, f->disks, (size_t)f->n_disks, &d.disks);
     // device copy of the materials with pad_ = "some lobe reads a non-constant texture": only then does k_shade
@@ -1036,56 +1234,34 @@ extern "C" int cray_trace(cray_ctx* c, cray_scene* s, const cray_ray* rays, size
 // Bvh::new(primitives, SplitMethod::SAH) on the device (cray_bvh_build.h): same nodes, same leaf order.
 // ---------------------------------------------------------------------------------------------
 namespace {
-struct DevMem {  // frees its allocations on every exit path
-    std::vector<void*> ptrs;
-    ~DevMem() { for (void* p : ptrs) (void)hipFree(p); }
-    template <class T> hipError_t get(T** out, size_t count) {
-        void* d = nullptr;
-        hipError_t e = hipMalloc(&d, (count ? count : 1) * sizeof(T));
-        if (e == hipSuccess) ptrs.push_back(d);
-        *out = (T*)d;
-        return e;
-    }
-};
-}  // namespace
-
-extern "C" int cray_bvh_build_sah(cray_ctx* c, const double* prim_bounds, uint32_t n, cray_bvh_node* out_nodes, uint32_t node_capacity,
-                                  uint32_t* out_n_nodes, uint32_t* out_prim_refs, cray_bvh_build_stats* stats) {
+// Bvh::new on device memory: d_box [n][6] -> DFS pre-order nodes + leaf order, both left on the device in `mem`.
+int bvh_build_device(cray_ctx* c, const double* d_box, uint32_t n, DevMem& mem, BvhOnDevice* r) {
     using namespace cray::bvhb;
-    if (!c || !prim_bounds || !out_nodes || !out_n_nodes || !out_prim_refs) { set_last_error("cray_bvh_build_sah: null argument"); return CRAY_ERR_INVALID; }
-    if (n == 0) { set_last_error("Bvh::new: no primitives"); return CRAY_ERR_BUILD; }
-    if (n >= (1u << 30)) { set_last_error("cray_bvh_build_sah: too many primitives"); return CRAY_ERR_UNSUPPORTED; }
-    for (size_t i = 0; i < (size_t)n * 6; i++)
-        if (!std::isfinite(prim_bounds[i])) { set_last_error("cray_bvh_build_sah: primitive %zu has a non-finite bound", i / 6); return CRAY_ERR_INVALID; }
-    HIP_TRY(hipSetDevice(c->device));
-    auto t_begin = std::chrono::steady_clock::now();
     hipStream_t st = c->stream;
-    DevMem mem;
-    double* d_box; uint32_t *d_order, *d_T, *d_tmp, *d_active[2], *d_small, *d_tile, *d_total, *d_reccnt;
+    uint32_t *d_order, *d_T, *d_tmp, *d_active[2], *d_small, *d_tile, *d_total, *d_reccnt;
     int32_t* d_slot_of; uint8_t *d_bidx, *d_flag;
     TopNode* d_top; SmallRec* d_pool; Slot* d_slots[2]; Ctl* d_ctl; cray_bvh_node* d_out;
     const size_t max_active = (size_t)n / (kSmall + 1) + 2;
     const uint32_t n_tiles = (n + kScanTile - 1) / kScanTile;
-    HIP_TRY(mem.get(&d_box, (size_t)n * 6));
+    DevMem tmp;  // scratch of the build, released when it returns; the results live in `mem`
     HIP_TRY(mem.get(&d_order, n));
-    HIP_TRY(mem.get(&d_slot_of, n));
-    HIP_TRY(mem.get(&d_bidx, n));
-    HIP_TRY(mem.get(&d_flag, n));
-    HIP_TRY(mem.get(&d_T, (size_t)n + 1));
-    HIP_TRY(mem.get(&d_tmp, n));
-    HIP_TRY(mem.get(&d_tile, n_tiles));
-    HIP_TRY(mem.get(&d_total, 1));
-    HIP_TRY(mem.get(&d_active[0], max_active));
-    HIP_TRY(mem.get(&d_active[1], max_active));
-    HIP_TRY(mem.get(&d_slots[0], max_active));
-    HIP_TRY(mem.get(&d_slots[1], max_active));
-    HIP_TRY(mem.get(&d_small, n));
-    HIP_TRY(mem.get(&d_reccnt, n));
-    HIP_TRY(mem.get(&d_top, (size_t)2 * n));
-    HIP_TRY(mem.get(&d_pool, (size_t)2 * n));
-    HIP_TRY(mem.get(&d_ctl, 1));
     HIP_TRY(mem.get(&d_out, (size_t)2 * n));
-    HIP_TRY(hipMemcpyAsync(d_box, prim_bounds, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(tmp.get(&d_slot_of, n));
+    HIP_TRY(tmp.get(&d_bidx, n));
+    HIP_TRY(tmp.get(&d_flag, n));
+    HIP_TRY(tmp.get(&d_T, (size_t)n + 1));
+    HIP_TRY(tmp.get(&d_tmp, n));
+    HIP_TRY(tmp.get(&d_tile, n_tiles));
+    HIP_TRY(tmp.get(&d_total, 1));
+    HIP_TRY(tmp.get(&d_active[0], max_active));
+    HIP_TRY(tmp.get(&d_active[1], max_active));
+    HIP_TRY(tmp.get(&d_slots[0], max_active));
+    HIP_TRY(tmp.get(&d_slots[1], max_active));
+    HIP_TRY(tmp.get(&d_small, n));
+    HIP_TRY(tmp.get(&d_reccnt, n));
+    HIP_TRY(tmp.get(&d_top, (size_t)2 * n));
+    HIP_TRY(tmp.get(&d_pool, (size_t)2 * n));
+    HIP_TRY(tmp.get(&d_ctl, 1));
     hipEvent_t ev0, ev1;
     HIP_TRY(hipEventCreate(&ev0));
     HIP_TRY(hipEventCreate(&ev1));
@@ -1098,7 +1274,12 @@ extern "C" int cray_bvh_build_sah(cray_ctx* c, const double* prim_bounds, uint32
     Ctl h{};
     int cur = 0;
     int rc = CRAY_OK;
-    while (n_active > 0) {
+    auto sync_ctl = [&](Ctl* dst) -> int {
+        HIP_TRY(hipMemcpyAsync(dst, d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return CRAY_OK;
+    };
+    while (n_active > 0 && rc == CRAY_OK) {
         if (++levels > 4096) { set_last_error("cray_bvh_build_sah: tree deeper than 4096 levels above the %u-primitive subtrees", kSmall); rc = CRAY_ERR_UNSUPPORTED; break; }
         const dim3 grid_a((n_active + kTB - 1) / kTB);
         // only the root reduces its bounds from the primitives; below it they come from the parent's SAH buckets (k_children)
@@ -1114,47 +1295,36 @@ extern "C" int cray_bvh_build_sah(cray_ctx* c, const double* prim_bounds, uint32
         hipLaunchKernelGGL(k_swap, grid_n, blk, 0, st, d_slot_of, d_slots[cur], d_top, d_flag, d_T, d_tmp, d_order, d_bidx, n);
         hipLaunchKernelGGL(k_children, grid_a, blk, 0, st, d_top, d_slots[cur], d_slots[cur ^ 1], n_active, d_T, d_active[cur ^ 1], d_small, d_ctl);
         hipLaunchKernelGGL(k_reslot, grid_n, blk, 0, st, d_slot_of, d_slots[cur], d_top, n);
-        HIP_TRY(hipMemcpyAsync(&h, d_ctl, sizeof(h), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        if ((rc = sync_ctl(&h))) break;
         if (h.error) break;
         n_active = h.n_next;
         if (n_active > max_active) { set_last_error("cray_bvh_build_sah: internal error (active list overflow)"); rc = CRAY_ERR_INVALID; break; }
         const unsigned int zero = 0;
-        HIP_TRY(hipMemcpyAsync(&d_ctl->n_next, &zero, sizeof(zero), hipMemcpyHostToDevice, st));
+        if (hipMemcpyAsync(&d_ctl->n_next, &zero, sizeof(zero), hipMemcpyHostToDevice, st) != hipSuccess) { set_last_error("hipMemcpyAsync failed"); rc = CRAY_ERR_HIP; break; }
         cur ^= 1;
     }
-    if (rc == CRAY_OK && !h.error) {
-        HIP_TRY(hipMemcpyAsync(&h, d_ctl, sizeof(h), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        HIP_TRY(hipMemsetAsync(d_flag, 0, n, st));
+    uint32_t n_leaves = 0;
+    if (rc == CRAY_OK && !h.error && (rc = sync_ctl(&h)) == CRAY_OK) {
+        hipError_t e = hipMemsetAsync(d_flag, 0, n, st);
         hipLaunchKernelGGL(k_small, dim3((h.n_small + 63) / 64), dim3(64), 0, st, d_box, d_order, d_top, d_small, h.n_small, d_pool, d_reccnt, d_flag, d_ctl);
         hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles), blk, 0, st, d_flag, d_T, d_tile, n);
         hipLaunchKernelGGL(k_scan_sums, dim3(1), blk, 0, st, d_tile, n_tiles, d_total);
         hipLaunchKernelGGL(k_scan_add, grid_n, blk, 0, st, d_T, d_tile, d_total, n);
         hipLaunchKernelGGL(k_emit_top, dim3((h.n_top + kTB - 1) / kTB), blk, 0, st, d_top, h.n_top, d_T, d_out);
         hipLaunchKernelGGL(k_emit_small, dim3((h.n_small + kTB - 1) / kTB), blk, 0, st, d_top, d_small, h.n_small, d_pool, d_reccnt, d_T, d_out);
-        HIP_TRY(hipEventRecord(ev1, st));
-        uint32_t n_leaves = 0;
+        if (e == hipSuccess) e = hipEventRecord(ev1, st);
         Ctl h2{};
-        HIP_TRY(hipMemcpyAsync(&n_leaves, d_T + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(&h2, d_ctl, sizeof(h2), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        if (e == hipSuccess) e = hipMemcpyAsync(&n_leaves, d_T + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(&h2, d_ctl, sizeof(h2), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { set_last_error("Bvh::new on the device failed: %s", hipGetErrorString(e)); rc = CRAY_ERR_HIP; }
         h.error = h2.error;
-        if (!h.error) {
-            const uint32_t n_nodes = 2 * n_leaves - 1;
-            if (n_nodes > node_capacity) { set_last_error("cray_bvh_build_sah: %u nodes do not fit the caller's %u", n_nodes, node_capacity); rc = CRAY_ERR_INVALID; }
-            else {
-                float ms = 0.f;
-                HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
-                HIP_TRY(hipMemcpy(out_nodes, d_out, (size_t)n_nodes * sizeof(cray_bvh_node), hipMemcpyDeviceToHost));
-                HIP_TRY(hipMemcpy(out_prim_refs, d_order, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-                *out_n_nodes = n_nodes;
-                if (stats) {
-                    stats->device_seconds = ms * 1e-3;
-                    stats->total_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
-                    stats->levels = levels; stats->top_nodes = h.n_top; stats->small_subtrees = h.n_small; stats->leaves = n_leaves;
-                }
-            }
+        if (rc == CRAY_OK && !h.error) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, ev0, ev1);
+            r->d_nodes = d_out; r->d_order = d_order; r->n_nodes = 2 * n_leaves - 1;
+            r->stats.device_seconds = ms * 1e-3;
+            r->stats.levels = levels; r->stats.top_nodes = h.n_top; r->stats.small_subtrees = h.n_small; r->stats.leaves = n_leaves;
         }
     }
     (void)hipEventDestroy(ev0);
@@ -1163,6 +1333,34 @@ extern "C" int cray_bvh_build_sah(cray_ctx* c, const double* prim_bounds, uint32
     if (h.error) {
         set_last_error("Bvh::new would panic in the reference (code %u: 1 zero surface area, 2 non-finite cost, 3 empty partition)", h.error);
         return CRAY_ERR_BUILD;
+    }
+    return CRAY_OK;
+}
+}  // namespace
+
+extern "C" int cray_bvh_build_sah(cray_ctx* c, const double* prim_bounds, uint32_t n, cray_bvh_node* out_nodes, uint32_t node_capacity,
+                                  uint32_t* out_n_nodes, uint32_t* out_prim_refs, cray_bvh_build_stats* stats) {
+    if (!c || !prim_bounds || !out_nodes || !out_n_nodes || !out_prim_refs) { set_last_error("cray_bvh_build_sah: null argument"); return CRAY_ERR_INVALID; }
+    if (n == 0) { set_last_error("Bvh::new: no primitives"); return CRAY_ERR_BUILD; }
+    if (n >= (1u << 30)) { set_last_error("cray_bvh_build_sah: too many primitives"); return CRAY_ERR_UNSUPPORTED; }
+    for (size_t i = 0; i < (size_t)n * 6; i++)
+        if (!std::isfinite(prim_bounds[i])) { set_last_error("cray_bvh_build_sah: primitive %zu has a non-finite bound", i / 6); return CRAY_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(c->device));
+    auto t_begin = std::chrono::steady_clock::now();
+    DevMem mem;
+    double* d_box;
+    HIP_TRY(mem.get(&d_box, (size_t)n * 6));
+    HIP_TRY(hipMemcpyAsync(d_box, prim_bounds, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    BvhOnDevice r{};
+    int rc = bvh_build_device(c, d_box, n, mem, &r);
+    if (rc != CRAY_OK) return rc;
+    if (r.n_nodes > node_capacity) { set_last_error("cray_bvh_build_sah: %u nodes do not fit the caller's %u", r.n_nodes, node_capacity); return CRAY_ERR_INVALID; }
+    HIP_TRY(hipMemcpy(out_nodes, r.d_nodes, (size_t)r.n_nodes * sizeof(cray_bvh_node), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_prim_refs, r.d_order, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    *out_n_nodes = r.n_nodes;
+    if (stats) {
+        *stats = r.stats;
+        stats->total_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     }
     return CRAY_OK;
 }

@@ -305,6 +305,7 @@ struct cray_host_scene {
     std::vector<cray_xf_shape> spheres, disks;
     std::vector<double> cdf;
     std::vector<int32_t> first_equal;
+    std::vector<cray_prim_bound> other_bounds;   // resident build: boxes of the non-triangle primitives
     double build_seconds;
     double bvh_seconds = 0.0;
     cray_bvh_build_stats gpu_build{};
@@ -314,7 +315,17 @@ extern "C" int cray_host_scene_new(const cray_scene_desc* d, int split_method, c
     return cray_host_scene_new_on(d, split_method, nullptr, out);
 }
 
+static int scene_new_impl(const cray_scene_desc* d, int split_method, cray_ctx* bvh_ctx, bool resident, cray_host_scene** out);
+
 extern "C" int cray_host_scene_new_on(const cray_scene_desc* d, int split_method, cray_ctx* bvh_ctx, cray_host_scene** out) {
+    return scene_new_impl(d, split_method, bvh_ctx, false, out);
+}
+
+extern "C" int cray_host_scene_new_resident(const cray_scene_desc* d, cray_host_scene** out) {
+    return scene_new_impl(d, CRAY_SPLIT_SAH, nullptr, true, out);
+}
+
+static int scene_new_impl(const cray_scene_desc* d, int split_method, cray_ctx* bvh_ctx, bool resident, cray_host_scene** out) {
     using namespace cray;
     if (!d || !out) { set_last_error("cray_host_scene_new: null argument"); return CRAY_ERR_INVALID; }
     if (bvh_ctx && split_method != CRAY_SPLIT_SAH) { set_last_error("the GPU builder implements SplitMethod::SAH only"); return CRAY_ERR_UNSUPPORTED; }
@@ -346,14 +357,22 @@ extern "C" int cray_host_scene_new_on(const cray_scene_desc* d, int split_method
     }
 
     // --- primitive bounds (shape.rs:402-438) and Bvh::new (bvh.rs:38-56)
-    std::vector<Item> items(d->n_prims);
+    // Resident build: the tree is built by cray_scene_upload on the GPU, triangle bounds included; the host only keeps the
+    // boxes of the other shapes (their transformations live here) and — when a Distant / Infinite light needs the world
+    // radius for its power (light.rs:170-177, scene.rs:42) — the union of all boxes.
+    bool need_world = !resident;
+    for (uint32_t i = 0; i < d->n_lights; i++)
+        if (d->lights[i].kind == CRAY_LIGHT_DISTANT || d->lights[i].kind == CRAY_LIGHT_INFINITE) need_world = true;
+    std::vector<Item> items(resident ? 0 : d->n_prims);
+    box3 world;
+    bool world_set = false;
     for (uint32_t i = 0; i < d->n_prims; i++) {
         const cray_prim& p = d->prims[i];
         box3 b;
         bool ok = true;
         if (p.shape_kind == CRAY_SHAPE_TRIANGLE) {
             ok = p.shape < d->n_triangles;
-            if (ok) {
+            if (ok && need_world) {
                 const cray_triangle& t = d->triangles[p.shape];
                 vec3 v0 = mk(t.v0.x, t.v0.y, t.v0.z);
                 vec3 v1 = v0 + mk(t.e1.x, t.e1.y, t.e1.z), v2 = v0 + mk(t.e2.x, t.e2.y, t.e2.z);
@@ -381,14 +400,24 @@ extern "C" int cray_host_scene_new_on(const cray_scene_desc* d, int split_method
             delete hs;
             return CRAY_ERR_INVALID;
         }
+        if (need_world) { world = world_set ? join(world, b) : b; world_set = true; }
+        if (resident) {
+            if (p.shape_kind != CRAY_SHAPE_TRIANGLE) {
+                cray_prim_bound ob;
+                ob.prim = i; ob.pad_ = 0;
+                ob.bmin[0] = b.lo.x; ob.bmin[1] = b.lo.y; ob.bmin[2] = b.lo.z; ob.bmax[0] = b.hi.x; ob.bmax[1] = b.hi.y; ob.bmax[2] = b.hi.z;
+                hs->other_bounds.push_back(ob);
+            }
+            continue;
+        }
         items[i].prim = i;
         items[i].box = b;
         items[i].centroid = mk((b.lo.x + b.hi.x) * 0.5, (b.lo.y + b.hi.y) * 0.5, (b.lo.z + b.hi.z) * 0.5);
     }
-    box3 world = items[0].box;
-    for (size_t i = 1; i < items.size(); i++) world = join(world, items[i].box);
     auto t_bvh = std::chrono::steady_clock::now();
-    if (bvh_ctx) {
+    if (resident) {
+        // nothing here: cray_scene_upload builds the tree (flat.build_on_device)
+    } else if (bvh_ctx) {
         // Bvh::new on the GPU (cray_bvh_build_sah, cray.h): same tree as Builder::sah below
         std::vector<double> pb((size_t)d->n_prims * 6);
         for (uint32_t i = 0; i < d->n_prims; i++) {
@@ -420,7 +449,7 @@ extern "C" int cray_host_scene_new_on(const cray_scene_desc* d, int split_method
     hs->bvh_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_bvh).count();
 
     // --- LightSampler::new (light.rs:187-200) with Light::power (:170-177), world_radius (scene.rs:42)
-    double world_radius = len(world.hi - world.lo) * 0.5;
+    double world_radius = need_world ? len(world.hi - world.lo) * 0.5 : 0.0;   // only read for Distant / Infinite lights
     hs->cdf.resize(d->n_lights);
     double total_power = 0.0;
     for (uint32_t i = 0; i < d->n_lights; i++) {
@@ -518,6 +547,9 @@ extern "C" int cray_host_scene_new_on(const cray_scene_desc* d, int split_method
     f.n_lights = d->n_lights; f.lights = d->lights;
     f.light_cdf = hs->cdf.data();
     f.first_equal_light = hs->first_equal.data();
+    f.build_on_device = resident ? 1u : 0u;
+    f.n_other_bounds = (uint32_t)hs->other_bounds.size();
+    f.other_bounds = hs->other_bounds.data();
     hs->build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     *out = hs;
     return CRAY_OK;

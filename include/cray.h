@@ -87,7 +87,16 @@ typedef struct {
     uint32_t n_lights;    const cray_light* lights;
     const double* light_cdf;            /* LightSampler.cdfs, n_lights entries */
     const int32_t* first_equal_light;   /* lights.iter().position(|l| l == light), path_integrator.rs:116 */
+    /* ABI 2 — resident build.  With build_on_device != 0 the scene comes WITHOUT a tree (n_nodes = n_prim_refs = 0):
+     * cray_scene_upload computes the primitive bounds (shape.rs:402-438) and runs Bvh::new(.., SAH) (bvh.rs:38-56, 234-336)
+     * on the GPU — the same tree cray_bvh_build_sah returns — and derives the traversal layout from it in place; the
+     * 0.9 GB of nodes never visit the host.  Triangle bounds are computed on the device from `triangles`; the bounds of
+     * the other primitives (spheres, disks: they need the host's transformation code) come in other_bounds. */
+    uint32_t build_on_device;
+    uint32_t n_other_bounds;
+    const struct cray_prim_bound* other_bounds;
 } cray_flat_scene;
+typedef struct cray_prim_bound { uint32_t prim, pad_; double bmin[3], bmax[3]; } cray_prim_bound;
 
 /* ---- render ----------------------------------------------------------------- */
 typedef struct {
@@ -193,6 +202,9 @@ typedef struct {
 } cray_bvh_build_stats;
 int cray_bvh_build_sah(cray_ctx* ctx, const double* prim_bounds, uint32_t n, cray_bvh_node* out_nodes, uint32_t node_capacity,
                        uint32_t* out_n_nodes, uint32_t* out_prim_refs, cray_bvh_build_stats* stats);
+/* Figures of the Bvh::new that ran inside cray_scene_upload for a resident build (cray_flat_scene.build_on_device);
+ * zeros for a scene uploaded with its tree. */
+void cray_scene_build_stats(const cray_scene* scene, cray_bvh_build_stats* out);
 
 /* ---- multi-GPU: pixel-tile shard + gather of Film tiles over RCCL / xGMI -----------------------------
  * Replaces the reference's merge point, the shared `Mutex<Vec<f32>>` every worker thread adds its tile into

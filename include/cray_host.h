@@ -31,6 +31,10 @@ int cray_host_scene_new(const cray_scene_desc* desc, int split_method, cray_host
 /* Same, with Bvh::new running on the GPU of `bvh_ctx` (cray_bvh_build_sah, cray.h; SAH only). The tree is
  * the one cray_host_scene_new builds; NULL = build on the host. */
 int cray_host_scene_new_on(const cray_scene_desc* desc, int split_method, cray_ctx* bvh_ctx, cray_host_scene** out);
+/* Scene::new for a RESIDENT build: everything but Bvh::new, which cray_scene_upload then runs on the GPU (triangle bounds,
+ * SAH tree and traversal layout all stay in HBM: cray_flat_scene.build_on_device in cray.h).  The flat scene carries no
+ * nodes; it is the fastest way from a cray_scene_desc to a renderable cray_scene (7.2 M triangles: DESIGN.md §10). */
+int cray_host_scene_new_resident(const cray_scene_desc* desc, cray_host_scene** out);
 /* The flat view stays valid until cray_host_scene_free; it borrows the desc's
  * material/texture/image/triangle arrays, which must outlive it too. */
 const cray_flat_scene* cray_host_scene_flat(const cray_host_scene* scene);
