@@ -422,13 +422,23 @@ class DeviceScene:
         _check(lib().cray_render_samples(self.ctx._h, self._h, C.byref(p), out.ctypes.data), 'cray_render_samples')
         return out
 
-    def trace(self, rays, any_hit=False):
+    def trace(self, rays, any_hit=False, timed=False):
+        """Scene::intersect / Scene::intersects for a batch of rays [n, 7] (o, d, tmax).  timed=True runs the instantiation
+        the frame loop times (no traversal counters) instead of the instrumented one."""
         rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 7)
         hits = np.zeros(len(rays), dtype=HIT_DT)
         st = Stats()
         _check(lib().cray_trace(self.ctx._h, self._h, rays.ctypes.data, len(rays), hits.ctypes.data,
-                                1 if any_hit else 0, C.byref(st)), 'cray_trace')
+                                (1 if any_hit else 0) + (2 if timed else 0), C.byref(st)), 'cray_trace')
         return hits, st.as_dict()
+
+    def trace_mixed(self, rays):
+        """k_trace_mixed as the frame loop launches it: every ray as a shadow ray (its tmax) and as a path segment (tmax = inf)
+        in ONE launch -> (any-hit answers [n], closest-hit records [n])."""
+        rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 7)
+        hits = np.zeros(2 * len(rays), dtype=HIT_DT)
+        _check(lib().cray_trace(self.ctx._h, self._h, rays.ctypes.data, len(rays), hits.ctypes.data, 4, None), 'cray_trace')
+        return hits[:len(rays)], hits[len(rays):]
 
     def close(self):
         if self._h:

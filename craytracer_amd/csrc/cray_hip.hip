@@ -1160,29 +1160,35 @@ extern "C" int cray_render_samples(cray_ctx* c, cray_scene* s, const cray_render
     return CRAY_OK;
 }
 
-extern "C" int cray_trace(cray_ctx* c, cray_scene* s, const cray_ray* rays, size_t n, cray_hit* hits, int any_hit, cray_stats* stats) {
+extern "C" int cray_trace(cray_ctx* c, cray_scene* s, const cray_ray* rays, size_t n, cray_hit* hits, int mode, cray_stats* stats) {
     if (!c || !s || (!rays && n) || (!hits && n)) { set_last_error("cray_trace: null argument"); return CRAY_ERR_INVALID; }
     if (s->ctx != c) { set_last_error("scene was uploaded through a different context"); return CRAY_ERR_INVALID; }
-    if (n >= ((size_t)1 << 31)) { set_last_error("cray_trace: too many rays in one call"); return CRAY_ERR_UNSUPPORTED; }
+    if (n >= ((size_t)1 << 30)) { set_last_error("cray_trace: too many rays in one call"); return CRAY_ERR_UNSUPPORTED; }
+    if (mode < CRAY_TRACE_CLOSEST || mode > CRAY_TRACE_MIXED_TIMED) { set_last_error("cray_trace: unknown mode %d", mode); return CRAY_ERR_INVALID; }
     HIP_TRY(hipSetDevice(c->device));
     if (n == 0) { if (stats) memset(stats, 0, sizeof(*stats)); return CRAY_OK; }
+    const bool mixed = mode == CRAY_TRACE_MIXED_TIMED;
+    const bool do_any = mode == CRAY_TRACE_ANY || mode == CRAY_TRACE_ANY_TIMED || mixed;
+    const bool do_closest = mode == CRAY_TRACE_CLOSEST || mode == CRAY_TRACE_CLOSEST_TIMED || mixed;
     int e;
     if ((e = ensure_state(c, n))) return e;
     std::vector<double> col(n);
     PathState& ps = c->ps;
-    double* dst_o[3] = {any_hit ? ps.sox : ps.ox, any_hit ? ps.soy : ps.oy, any_hit ? ps.soz : ps.oz};
-    double* dst_d[3] = {any_hit ? ps.sdx : ps.dx, any_hit ? ps.sdy : ps.dy, any_hit ? ps.sdz : ps.dz};
     for (int k = 0; k < 3; k++) {
+        double* o_closest[3] = {ps.ox, ps.oy, ps.oz}; double* d_closest[3] = {ps.dx, ps.dy, ps.dz};
+        double* o_any[3] = {ps.sox, ps.soy, ps.soz}; double* d_any[3] = {ps.sdx, ps.sdy, ps.sdz};
         for (size_t i = 0; i < n; i++) col[i] = rays[i].o[k];
-        HIP_TRY(hipMemcpy(dst_o[k], col.data(), n * 8, hipMemcpyHostToDevice));
+        if (do_closest) HIP_TRY(hipMemcpy(o_closest[k], col.data(), n * 8, hipMemcpyHostToDevice));
+        if (do_any) HIP_TRY(hipMemcpy(o_any[k], col.data(), n * 8, hipMemcpyHostToDevice));
         for (size_t i = 0; i < n; i++) col[i] = rays[i].d[k];
-        HIP_TRY(hipMemcpy(dst_d[k], col.data(), n * 8, hipMemcpyHostToDevice));
+        if (do_closest) HIP_TRY(hipMemcpy(d_closest[k], col.data(), n * 8, hipMemcpyHostToDevice));
+        if (do_any) HIP_TRY(hipMemcpy(d_any[k], col.data(), n * 8, hipMemcpyHostToDevice));
     }
     for (size_t i = 0; i < n; i++) col[i] = rays[i].tmax;
     HIP_TRY(hipMemcpy(ps.stmax, col.data(), n * 8, hipMemcpyHostToDevice));
     if ((e = reset_counters(c))) return e;
     // any-hit resolution adds `contribution` to L: use L as the "unoccluded" flag (0 + 1)
-    if (any_hit) {
+    if (do_any) {
         for (size_t i = 0; i < n; i++) col[i] = 0.0;
         HIP_TRY(hipMemcpy(ps.lr, col.data(), n * 8, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(ps.lg, col.data(), n * 8, hipMemcpyHostToDevice));
@@ -1193,8 +1199,30 @@ extern "C" int cray_trace(cray_ctx* c, cray_scene* s, const cray_ray* rays, size
         HIP_TRY(hipMemcpy(ps.cr, col.data(), n * 8, hipMemcpyHostToDevice));
     }
     const int g = grid_for(c, n, 8);
-    if (any_hit) {
-        hipLaunchKernelGGL((k_trace<true, true>), dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)nullptr, (const unsigned int*)nullptr, (uint32_t)n, (const double*)nullptr, c->counters, &c->counters->trace_head, c->refill_min);
+    Counters* ctr = c->counters;
+    if (mixed) {
+        // k_trace_mixed as the frame loop launches it: positions [0, n) of the virtual queue are the shadow rays of paths
+        // 0..n-1 (an identity queue), positions [n, 2n) the path segments of the same paths (tmax = +inf, like Ray::new)
+        std::vector<uint32_t> iota(n);
+        for (size_t i = 0; i < n; i++) iota[i] = (uint32_t)i;
+        const unsigned int cnt = (unsigned int)n;
+        HIP_TRY(hipMemcpy(c->shadow_queue, iota.data(), n * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(&ctr->n_shadow, &cnt, sizeof(cnt), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(&ctr->n_active[0], &cnt, sizeof(cnt), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_trace_mixed, dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow,
+                           (const uint32_t*)nullptr, (const unsigned int*)&ctr->n_active[0], ctr, &ctr->trace_head, c->refill_min);
+    } else if (mode == CRAY_TRACE_ANY) {
+        hipLaunchKernelGGL((k_trace<true, true>), dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)nullptr, (const unsigned int*)nullptr, (uint32_t)n, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
+    } else if (mode == CRAY_TRACE_ANY_TIMED) {
+        hipLaunchKernelGGL((k_trace<true, false>), dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)nullptr, (const unsigned int*)nullptr, (uint32_t)n, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
+    } else if (mode == CRAY_TRACE_CLOSEST) {
+        // closest hit with caller-supplied tmax: rays whose tmax is finite go through the same kernel via stmax
+        hipLaunchKernelGGL((k_trace<false, true>), dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)nullptr, (const unsigned int*)nullptr, (uint32_t)n, (const double*)ps.stmax, ctr, &ctr->trace_head, c->refill_min);
+    } else {
+        hipLaunchKernelGGL((k_trace<false, false>), dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)nullptr, (const unsigned int*)nullptr, (uint32_t)n, (const double*)ps.stmax, ctr, &ctr->trace_head, c->refill_min);
+    }
+    cray_hit* closest_out = mixed ? hits + n : hits;
+    if (do_any) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipMemcpy(col.data(), ps.lr, n * 8, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < n; i++) {
@@ -1202,14 +1230,13 @@ extern "C" int cray_trace(cray_ctx* c, cray_scene* s, const cray_ray* rays, size
             hits[i].hit = col[i] == 0.0 ? 1 : 0;
             hits[i].prim = -1;
         }
-    } else {
-        // closest hit with caller-supplied tmax: rays whose tmax is finite go through the same kernel via stmax
-        hipLaunchKernelGGL((k_trace<false, true>), dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)nullptr, (const unsigned int*)nullptr, (uint32_t)n, (const double*)ps.stmax, c->counters, &c->counters->trace_head, c->refill_min);
+    }
+    if (do_closest) {
         cray_hit* d_hits = nullptr;
         HIP_TRY(hipMalloc((void**)&d_hits, n * sizeof(cray_hit)));
         hipLaunchKernelGGL(k_hit_records, dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (uint32_t)n, d_hits);
         hipError_t err = hipStreamSynchronize(c->stream);
-        if (err == hipSuccess) err = hipMemcpy(hits, d_hits, n * sizeof(cray_hit), hipMemcpyDeviceToHost);
+        if (err == hipSuccess) err = hipMemcpy(closest_out, d_hits, n * sizeof(cray_hit), hipMemcpyDeviceToHost);
         (void)hipFree(d_hits);
         if (err != hipSuccess) { set_last_error("cray_trace failed: %s", hipGetErrorString(err)); return CRAY_ERR_HIP; }
     }
@@ -1218,7 +1245,7 @@ extern "C" int cray_trace(cray_ctx* c, cray_scene* s, const cray_ray* rays, size
     if (h.stack_overflow) {
         if (c->deep_depth == 0) {
             if ((e = ensure_deep(c))) return e;
-            return cray_trace(c, s, rays, n, hits, any_hit, stats);
+            return cray_trace(c, s, rays, n, hits, mode, stats);
         }
         set_last_error("BVH deeper than the %u-entry traversal stack", (unsigned)kStackDepth + c->deep_depth);
         return CRAY_ERR_UNSUPPORTED;

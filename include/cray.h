@@ -184,8 +184,15 @@ void cray_render_params_default(cray_render_params* params);
  * out_L[(y*W + x)*n + (s - sample_begin)][3] f64, host memory. */
 int cray_render_samples(cray_ctx* ctx, cray_scene* scene, const cray_render_params* params, double* out_L);
 
-/* Replaces Scene::intersect (any_hit = 0) / Scene::intersects (any_hit = 1), scene.rs:55-61. */
-int cray_trace(cray_ctx* ctx, cray_scene* scene, const cray_ray* rays, size_t n, cray_hit* hits, int any_hit,
+/* Replaces Scene::intersect / Scene::intersects (scene.rs:55-61) for a batch of rays: the per-ray parity hook.
+ *   CRAY_TRACE_CLOSEST / CRAY_TRACE_ANY        the instrumented instantiations: stats carry the node / primitive counters
+ *   CRAY_TRACE_CLOSEST_TIMED / _ANY_TIMED      the very kernels the frame loop times (k_trace<*, false>), no counters
+ *   CRAY_TRACE_MIXED_TIMED                     k_trace_mixed as the frame loop launches it: every ray is traced as a shadow
+ *                                              ray (with its tmax) AND as a path segment (tmax = +inf, like Ray::new) in ONE
+ *                                              launch; hits[0..n) = the any-hit answers, hits[n..2n) = the closest-hit records
+ * Closest-hit modes honour rays[i].tmax except the mixed one. hits: n entries (2n for the mixed mode). */
+enum { CRAY_TRACE_CLOSEST = 0, CRAY_TRACE_ANY = 1, CRAY_TRACE_CLOSEST_TIMED = 2, CRAY_TRACE_ANY_TIMED = 3, CRAY_TRACE_MIXED_TIMED = 4 };
+int cray_trace(cray_ctx* ctx, cray_scene* scene, const cray_ray* rays, size_t n, cray_hit* hits, int mode,
                cray_stats* stats);
 
 /* Replaces Bvh::new(primitives, SplitMethod::SAH) (src/bvh.rs:38-56, 234-336) — the scene-load step that
