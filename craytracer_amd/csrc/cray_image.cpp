@@ -4,6 +4,8 @@
 // (src/obj.rs:16-24, src/texture.rs:57-58: `image::io::Reader::open(path).decode()`, `.to_rgb8()`).  This file reads
 // the two formats the path needs without any dependency:
 //   * binary / ASCII PNM (P6, P3, P5, P2) — exact by definition;
+//   * PNG: all colour types and bit depths, interlaced or not, with its own inflate (no zlib); alpha is dropped and 16-bit
+//     samples are scaled like the `image` crate's `to_rgb8` ((x + 128) / 257);
 //   * JPEG, 8-bit Huffman, baseline / extended sequential (SOF0, SOF1) and progressive (SOF2), 1 or 3 components,
 //     any sampling factors, restart intervals.  Arithmetic follows the IJG reference decoder (integer "islow" IDCT,
 //     triangle-filter "fancy" chroma upsampling for 2x1 / 2x2, the ycc -> rgb integer tables), so the pixels equal
@@ -88,6 +90,212 @@ int decode_pnm(const std::vector<uint8_t>& d, uint32_t* w, uint32_t* h, uint8_t*
     }
     if (!ok) { free(out); cray::set_last_error("PNM: truncated pixel data"); return CRAY_ERR_INVALID; }
     *w = (uint32_t)W; *h = (uint32_t)H; *rgb = out;
+    return CRAY_OK;
+}
+
+// ------------------------------------------------------------------------------------------- PNG
+// RFC 1951 inflate: stored, fixed and dynamic Huffman blocks
+struct Inflate {
+    const uint8_t* d; size_t n, pos = 0;
+    uint32_t bits = 0; int nbits = 0;
+    bool ok = true;
+    size_t limit = ~(size_t)0;   // the caller knows how many bytes the stream may legitimately expand to
+    int bit() {
+        if (nbits == 0) { if (pos >= n) { ok = false; return 0; } bits = d[pos++]; nbits = 8; }
+        int b = bits & 1; bits >>= 1; nbits--; return b;
+    }
+    uint32_t take(int k) { uint32_t v = 0; for (int i = 0; i < k; i++) v |= (uint32_t)bit() << i; return v; }
+    struct Table { uint16_t count[16], symbol[320]; };
+    static void build(Table& t, const uint8_t* len, int n_sym) {
+        memset(t.count, 0, sizeof(t.count));
+        for (int i = 0; i < n_sym; i++) t.count[len[i]]++;
+        t.count[0] = 0;
+        uint16_t offs[16]; offs[1] = 0;
+        for (int l = 1; l < 15; l++) offs[l + 1] = (uint16_t)(offs[l] + t.count[l]);
+        for (int i = 0; i < n_sym; i++) if (len[i]) t.symbol[offs[len[i]]++] = (uint16_t)i;
+    }
+    int decode(const Table& t) {
+        int code = 0, first = 0, index = 0;
+        for (int l = 1; l <= 15; l++) {
+            code |= bit();
+            const int count = t.count[l];
+            if (code - count < first) return t.symbol[index + (code - first)];
+            index += count; first += count; first <<= 1; code <<= 1;
+            if (!ok) return -1;
+        }
+        ok = false;
+        return -1;
+    }
+    bool run(std::vector<uint8_t>& out) {
+        static const uint16_t lbase[29] = {3,4,5,6,7,8,9,10,11,13,15,17,19,23,27,31,35,43,51,59,67,83,99,115,131,163,195,227,258};
+        static const uint8_t lext[29] = {0,0,0,0,0,0,0,0,1,1,1,1,2,2,2,2,3,3,3,3,4,4,4,4,5,5,5,5,0};
+        static const uint16_t dbase[30] = {1,2,3,4,5,7,9,13,17,25,33,49,65,97,129,193,257,385,513,769,1025,1537,2049,3073,4097,6145,8193,12289,16385,24577};
+        static const uint8_t dext[30] = {0,0,0,0,1,1,2,2,3,3,4,4,5,5,6,6,7,7,8,8,9,9,10,10,11,11,12,12,13,13};
+        for (;;) {
+            const int last = bit(), type = (int)take(2);
+            if (!ok) return false;
+            if (type == 0) {
+                nbits = 0;
+                if (pos + 4 > n) return false;
+                const uint32_t len = d[pos] | (d[pos + 1] << 8), nlen = d[pos + 2] | (d[pos + 3] << 8);
+                pos += 4;
+                if ((len ^ 0xffffu) != nlen || pos + len > n) return false;
+                if (out.size() + len > limit) return false;
+                out.insert(out.end(), d + pos, d + pos + len);
+                pos += len;
+            } else if (type == 1 || type == 2) {
+                Table lt, dt;
+                uint8_t lens[320];
+                if (type == 1) {
+                    for (int i = 0; i < 144; i++) lens[i] = 8;
+                    for (int i = 144; i < 256; i++) lens[i] = 9;
+                    for (int i = 256; i < 280; i++) lens[i] = 7;
+                    for (int i = 280; i < 288; i++) lens[i] = 8;
+                    build(lt, lens, 288);
+                    for (int i = 0; i < 30; i++) lens[i] = 5;
+                    build(dt, lens, 30);
+                } else {
+                    const int nl = (int)take(5) + 257, nd = (int)take(5) + 1, nc = (int)take(4) + 4;
+                    static const uint8_t order[19] = {16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15};
+                    uint8_t cl[19] = {0};
+                    for (int i = 0; i < nc; i++) cl[order[i]] = (uint8_t)take(3);
+                    if (!ok || nl > 286 || nd > 30) return false;
+                    Table ct;
+                    build(ct, cl, 19);
+                    int idx = 0;
+                    while (idx < nl + nd) {
+                        const int sym = decode(ct);
+                        if (sym < 0) return false;
+                        if (sym < 16) lens[idx++] = (uint8_t)sym;
+                        else {
+                            int prev = 0, rep;
+                            if (sym == 16) { if (idx == 0) return false; prev = lens[idx - 1]; rep = 3 + (int)take(2); }
+                            else if (sym == 17) rep = 3 + (int)take(3);
+                            else rep = 11 + (int)take(7);
+                            if (idx + rep > nl + nd) return false;
+                            while (rep--) lens[idx++] = (uint8_t)prev;
+                        }
+                    }
+                    if (lens[256] == 0) return false;
+                    build(lt, lens, nl);
+                    build(dt, lens + nl, nd);
+                }
+                for (;;) {
+                    int sym = decode(lt);
+                    if (sym < 0 || !ok) return false;
+                    if (out.size() > limit) return false;
+                    if (sym < 256) out.push_back((uint8_t)sym);
+                    else if (sym == 256) break;
+                    else {
+                        sym -= 257;
+                        if (sym >= 29) return false;
+                        const int len = lbase[sym] + (int)take(lext[sym]);
+                        const int ds = decode(dt);
+                        if (ds < 0 || ds >= 30) return false;
+                        const size_t dist = dbase[ds] + take(dext[ds]);
+                        if (!ok || dist > out.size()) return false;
+                        const size_t from = out.size() - dist;
+                        for (int i = 0; i < len; i++) out.push_back(out[from + i]);
+                    }
+                }
+            } else return false;
+            if (last) return ok;
+        }
+    }
+};
+
+int decode_png(const std::vector<uint8_t>& d, uint32_t* w_out, uint32_t* h_out, uint8_t** rgb) {
+    auto fail = [](const char* m) { cray::set_last_error("PNG: %s", m); return CRAY_ERR_INVALID; };
+    auto be32 = [&](size_t at) { return ((uint32_t)d[at] << 24) | ((uint32_t)d[at + 1] << 16) | ((uint32_t)d[at + 2] << 8) | d[at + 3]; };
+    size_t p = 8;
+    uint32_t W = 0, H = 0;
+    int depth = 0, ctype = -1, interlace = 0;
+    std::vector<uint8_t> idat, plte;
+    bool seen_end = false;
+    while (p + 12 <= d.size() && !seen_end) {
+        const uint32_t len = be32(p);
+        if (len > d.size() - p - 12) return fail("truncated chunk");
+        const char* ty = (const char*)&d[p + 4];
+        const size_t at = p + 8;
+        if (!memcmp(ty, "IHDR", 4)) {
+            if (len < 13) return fail("bad IHDR");
+            W = be32(at); H = be32(at + 4); depth = d[at + 8]; ctype = d[at + 9]; interlace = d[at + 12];
+            if (d[at + 10] != 0 || d[at + 11] != 0 || interlace > 1) return fail("unsupported compression / filter / interlace method");
+        } else if (!memcmp(ty, "PLTE", 4)) plte.assign(d.begin() + at, d.begin() + at + len);
+        else if (!memcmp(ty, "IDAT", 4)) idat.insert(idat.end(), d.begin() + at, d.begin() + at + len);
+        else if (!memcmp(ty, "IEND", 4)) seen_end = true;
+        p += 12 + (size_t)len;
+    }
+    const int channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    const bool depth_ok = (ctype == 0 && (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)) || (ctype == 3 && (depth == 1 || depth == 2 || depth == 4 || depth == 8)) ||
+                          ((ctype == 2 || ctype == 4 || ctype == 6) && (depth == 8 || depth == 16));
+    if (!channels || !depth_ok || W == 0 || H == 0 || (uint64_t)W * H > (1ull << 31)) return fail("bad header");
+    if (ctype == 3 && plte.size() < 3) return fail("palette image without PLTE");
+    if (idat.size() < 6) return fail("no image data");
+    Inflate z;
+    z.d = idat.data() + 2; z.n = idat.size() - 2;   // zlib header: CMF, FLG (no preset dictionary in PNG)
+    if ((idat[0] & 15) != 8 || (idat[1] & 0x20)) return fail("bad zlib header");
+    std::vector<uint8_t> raw;
+    const size_t row_bytes = ((size_t)W * channels * depth + 7) / 8;
+    z.limit = (size_t)H * (row_bytes + 1) + (interlace ? 8 * ((size_t)H + row_bytes) + 64 : 0) + 258;   // filter bytes included; Adam7 pads every sub-row
+    raw.reserve(z.limit < ((size_t)1 << 28) ? z.limit : ((size_t)1 << 28));
+    if (!z.run(raw)) return fail("corrupt deflate stream");
+    uint8_t* out = (uint8_t*)malloc((size_t)W * H * 3);
+    if (!out) return fail("out of memory");
+    const int bpp_bits = channels * depth, bpp = (bpp_bits + 7) / 8;   // bytes per complete pixel for the filters
+    auto sample16 = [](const uint8_t* q) { const uint32_t v = ((uint32_t)q[0] << 8) | q[1]; return (uint8_t)((v + 128) / 257); };
+    // one pass (the whole image, or one of the seven Adam7 sub-images): unfilter, then scatter into `out`
+    size_t rp = 0;
+    std::vector<uint8_t> prev, cur;
+    auto pass = [&](uint32_t x0, uint32_t y0, uint32_t dx, uint32_t dy) -> bool {
+        if (x0 >= W || y0 >= H) return true;
+        const uint32_t pw = (W - x0 + dx - 1) / dx, ph = (H - y0 + dy - 1) / dy;
+        const size_t stride = ((size_t)pw * bpp_bits + 7) / 8;
+        prev.assign(stride, 0); cur.resize(stride);
+        for (uint32_t r = 0; r < ph; r++) {
+            if (rp + 1 + stride > raw.size()) return false;
+            const int ft = raw[rp++];
+            const uint8_t* src = &raw[rp];
+            rp += stride;
+            for (size_t i = 0; i < stride; i++) {
+                const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= (size_t)bpp ? prev[i - bpp] : 0;
+                int pred = 0;
+                if (ft == 1) pred = a;
+                else if (ft == 2) pred = b;
+                else if (ft == 3) pred = (a + b) >> 1;
+                else if (ft == 4) { const int pa = abs(b - c), pb = abs(a - c), pc = abs(a + b - 2 * c); pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); }
+                else if (ft != 0) return false;
+                cur[i] = (uint8_t)(src[i] + pred);
+            }
+            const uint32_t y = y0 + r * dy;
+            for (uint32_t i = 0; i < pw; i++) {
+                uint8_t* o = out + ((size_t)y * W + (x0 + i * dx)) * 3;
+                if (depth < 8) {
+                    const size_t bit = (size_t)i * depth;
+                    const int v = (cur[bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1);
+                    if (ctype == 3) { if ((size_t)v * 3 + 2 < plte.size()) { o[0] = plte[v * 3]; o[1] = plte[v * 3 + 1]; o[2] = plte[v * 3 + 2]; } else { o[0] = o[1] = o[2] = 0; } }
+                    else { o[0] = o[1] = o[2] = (uint8_t)(v * 255 / ((1 << depth) - 1)); }
+                } else {
+                    const uint8_t* q = &cur[(size_t)i * bpp];
+                    const int sb = depth / 8;
+                    if (ctype == 3) { const size_t v = q[0]; if (v * 3 + 2 < plte.size()) { o[0] = plte[v * 3]; o[1] = plte[v * 3 + 1]; o[2] = plte[v * 3 + 2]; } else { o[0] = o[1] = o[2] = 0; } }
+                    else if (ctype == 0 || ctype == 4) { o[0] = o[1] = o[2] = depth == 8 ? q[0] : sample16(q); }
+                    else { for (int k = 0; k < 3; k++) o[k] = depth == 8 ? q[k] : sample16(q + k * sb); }
+                }
+            }
+            prev.swap(cur);
+            cur.resize(stride);
+        }
+        return true;
+    };
+    bool ok = true;
+    if (!interlace) ok = pass(0, 0, 1, 1);
+    else {
+        static const uint32_t ax[7] = {0, 4, 0, 2, 0, 1, 0}, ay[7] = {0, 0, 4, 0, 2, 0, 1}, adx[7] = {8, 8, 4, 4, 2, 2, 1}, ady[7] = {8, 8, 8, 4, 4, 2, 2};
+        for (int k = 0; k < 7 && ok; k++) ok = pass(ax[k], ay[k], adx[k], ady[k]);
+    }
+    if (!ok) { free(out); return fail("truncated or corrupt image data"); }
+    *w_out = W; *h_out = H; *rgb = out;
     return CRAY_OK;
 }
 
@@ -611,7 +819,9 @@ extern "C" int cray_load_image(const char* path, uint32_t* width, uint32_t* heig
     if (!read_whole_file(path, d)) { cray::set_last_error("cray_load_image: cannot read %s", path); return CRAY_ERR_INVALID; }
     if (d.size() >= 8 && d[0] == 'P' && (d[1] == '2' || d[1] == '3' || d[1] == '5' || d[1] == '6')) return decode_pnm(d, width, height, rgb8);
     if (d.size() >= 4 && d[0] == 0xff && d[1] == 0xd8) return decode_jpeg(d, width, height, rgb8);
-    cray::set_last_error("cray_load_image: %s is neither PNM nor JPEG (PNG and other formats need a caller-supplied cray_image_loader)", path);
+    static const uint8_t png_sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    if (d.size() >= 8 && memcmp(d.data(), png_sig, 8) == 0) return decode_png(d, width, height, rgb8);
+    cray::set_last_error("cray_load_image: %s is not PNM, PNG or JPEG (other formats need a caller-supplied cray_image_loader)", path);
     return CRAY_ERR_UNSUPPORTED;
 }
 

@@ -26,7 +26,8 @@ int cray_read_exr(const char* path, uint32_t* width, uint32_t* height, float* rg
 
 /* Texture files for hosts without an image library — what the reference does with the `image` crate
  * (`image::io::Reader::open(path).decode()` + `.to_rgb8()`, src/obj.rs:16-24, src/texture.rs:57-58):
- *   PNM (P6 / P3 / P5 / P2) and JPEG (8-bit Huffman: baseline, extended sequential and progressive; 1 or 3 components).
+ *   PNM (P6 / P3 / P5 / P2), PNG (every colour type and bit depth, Adam7, own inflate; alpha dropped, 16-bit scaled by
+ *   (x + 128) / 257 like the crate's to_rgb8) and JPEG (8-bit Huffman: baseline, extended sequential and progressive).
  * JPEG arithmetic is the IJG reference decoder's (islow IDCT, fancy upsampling), i.e. libjpeg-turbo's pixels; the Rust
  * jpeg-decoder may differ from it by a level or two.  *rgb8: malloc()-ed width*height*3 bytes, row-major; release with
  * cray_free_image (or free).  Returns 0, CRAY_ERR_INVALID (unreadable / corrupt) or CRAY_ERR_UNSUPPORTED (other formats). */

@@ -112,3 +112,102 @@ def test_reference_staircase_textures_decode_like_libjpeg_turbo():
         ours = backend.load_image(os.path.join(REF_TEX, f))
         theirs = np.asarray(Image.open(os.path.join(REF_TEX, f)).convert('RGB'))
         assert np.array_equal(ours, theirs), f
+
+
+# ---- PNG -----------------------------------------------------------------------------------------------------------
+def _png_cases():
+    rng = np.random.default_rng(4)
+    rgb = np.asarray(_picture(37, 23, 3))
+    yield 'rgb8', Image.fromarray(rgb), {}
+    yield 'rgb8-interlaced-optimised', Image.fromarray(rgb), {'optimize': True}
+    yield 'rgb8-uncompressed', Image.fromarray(rgb), {'compress_level': 0}          # stored deflate blocks
+    yield 'rgb8-level1', Image.fromarray(np.asarray(_picture(300, 200, 8))), {'compress_level': 1}
+    yield 'rgba8', Image.fromarray(np.dstack([rgb, rng.integers(0, 256, rgb.shape[:2], dtype=np.uint8)])), {}
+    yield 'gray8', Image.fromarray(rgb[..., 0]), {}
+    yield 'gray-alpha8', Image.fromarray(np.dstack([rgb[..., 0], rgb[..., 1]]), 'LA'), {}
+    yield 'gray1', Image.fromarray(rgb[..., 0]).convert('1'), {}
+    yield 'palette8', Image.fromarray(rgb).convert('P', palette=Image.ADAPTIVE, colors=200), {}
+    yield 'palette4', Image.fromarray(rgb).convert('P', palette=Image.ADAPTIVE, colors=16), {'bits': 4}
+    yield 'palette2', Image.fromarray(rgb).convert('P', palette=Image.ADAPTIVE, colors=4), {'bits': 2}
+    yield 'palette1', Image.fromarray(rgb).convert('P', palette=Image.ADAPTIVE, colors=2), {'bits': 1}
+    yield 'tiny', Image.fromarray(rgb[:1, :1]), {}
+    yield 'wide', Image.fromarray(np.asarray(_picture(1000, 3, 9))), {}
+
+
+@pytest.mark.parametrize('name', [c[0] for c in _png_cases()])
+def test_png_equals_pillow(tmp_path, name):
+    img, opts = next((c[1], c[2]) for c in _png_cases() if c[0] == name)
+    path = str(tmp_path / 'x.png')
+    img.save(path, 'PNG', **opts)
+    ours = backend.load_image(path)
+    theirs = np.asarray(Image.open(path).convert('RGB'))
+    assert ours.shape == theirs.shape and np.array_equal(ours, theirs)
+
+
+def test_png_interlaced_and_16_bit(tmp_path):
+    """Adam7 and 16-bit files are written by hand (Pillow writes neither): filters 0-4 mixed per row; 16-bit samples come out
+    as (x + 128) / 257, the `image` crate's to_rgb8."""
+    import struct, zlib
+    rng = np.random.default_rng(6)
+
+    def chunk(ty, body):
+        return struct.pack('>I', len(body)) + ty + body + struct.pack('>I', zlib.crc32(ty + body) & 0xffffffff)
+
+    def filt(rows, bpp):
+        out, prev = b'', np.zeros(len(rows[0]) if len(rows) else 0, np.int32)
+        for k, row in enumerate(rows):
+            cur = np.frombuffer(row, np.uint8).astype(np.int32)
+            ft = k % 5
+            a = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]]) if len(cur) > bpp else np.zeros_like(cur)
+            c = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]]) if len(cur) > bpp else np.zeros_like(cur)
+            if ft == 0: pred = np.zeros_like(cur)
+            elif ft == 1: pred = a
+            elif ft == 2: pred = prev
+            elif ft == 3: pred = (a + prev) // 2
+            else:
+                pa, pb, pc = abs(prev - c), abs(a - c), abs(a + prev - 2 * c)
+                pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, c))
+            out += bytes([ft]) + ((cur - pred) & 255).astype(np.uint8).tobytes()
+            prev = cur
+        return out
+
+    W, H = 21, 13
+    img16 = rng.integers(0, 65536, size=(H, W, 3), dtype=np.uint16)
+    rows = [img16[y].astype('>u2').tobytes() for y in range(H)]
+    png = b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', struct.pack('>IIBBBBB', W, H, 16, 2, 0, 0, 0)) + chunk(b'IDAT', zlib.compress(filt(rows, 6), 6)) + chunk(b'IEND', b'')
+    p16 = str(tmp_path / 'p16.png')
+    open(p16, 'wb').write(png)
+    assert np.array_equal(backend.load_image(p16), ((img16.astype(np.uint32) + 128) // 257).astype(np.uint8))
+
+    img8 = rng.integers(0, 256, size=(H, W, 4), dtype=np.uint8)     # RGBA, Adam7
+    data = b''
+    for x0, y0, dx, dy in [(0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)]:
+        sub = img8[y0::dy, x0::dx]
+        if sub.size:
+            data += filt([sub[r].tobytes() for r in range(sub.shape[0])], 4)
+    png = b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', struct.pack('>IIBBBBB', W, H, 8, 6, 0, 0, 1)) + chunk(b'IDAT', zlib.compress(data[:200])[:0] + zlib.compress(data)) + chunk(b'IEND', b'')
+    pi = str(tmp_path / 'adam7.png')
+    open(pi, 'wb').write(png)
+    assert np.array_equal(backend.load_image(pi), img8[..., :3])
+    assert np.array_equal(np.asarray(Image.open(pi).convert('RGB')), img8[..., :3])      # Pillow reads Adam7 the same way
+
+
+def test_damaged_png_files_are_errors(tmp_path):
+    path = str(tmp_path / 'x.png')
+    _picture(40, 30, 2).save(path, 'PNG')
+    data = open(path, 'rb').read()
+    rng = np.random.default_rng(10)
+    bad = str(tmp_path / 'bad.png')
+    for trial in range(80):
+        b = bytearray(data)
+        if trial % 3 == 0:
+            b = b[: int(rng.integers(8, len(b)))]
+        else:
+            for _ in range(int(rng.integers(1, 6))):
+                b[int(rng.integers(8, len(b)))] = int(rng.integers(0, 256))
+        open(bad, 'wb').write(bytes(b))
+        try:
+            out = backend.load_image(bad)
+            assert out.ndim == 3 and out.shape[2] == 3
+        except backend.CrayError:
+            pass
