@@ -85,7 +85,7 @@ ABI_SYMBOLS = ['cray_ctx_create', 'cray_ctx_destroy', 'cray_scene_upload', 'cray
                'cray_scene_info', 'cray_comm_unique_id', 'cray_comm_init', 'cray_comm_rank', 'cray_comm_world_size',
                'cray_comm_barrier', 'cray_comm_allreduce_f64', 'cray_scene_broadcast', 'cray_render_gather',
                'cray_film_gather', 'cray_film_pack', 'cray_film_unpack', 'cray_measure_stream_read', 'cray_load_image', 'cray_free_image', 'cray_default_image_loader', 'cray_set_sobol_vectors',
-               'cray_host_scene_new_resident', 'cray_scene_build_stats']
+               'cray_host_scene_new_resident', 'cray_scene_build_stats', 'cray_preview_checkerboard', 'cray_preview_pixels']
 
 _lib = None
 #: how the loaded library came to be: 'shipped' (the .so in the tree was current), 'rebuilt' (sources were newer, hipcc ran),
@@ -160,6 +160,10 @@ def lib():
     L.cray_free_image.restype = None
     L.cray_free_image.argtypes = [C.c_void_p]
     L.cray_set_sobol_vectors.argtypes = [C.c_void_p]
+    L.cray_preview_checkerboard.restype = None
+    L.cray_preview_checkerboard.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.cray_preview_pixels.restype = None
+    L.cray_preview_pixels.argtypes = [C.c_void_p, C.c_uint64, C.c_double, C.c_void_p]
     L.cray_measure_stream_read.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_double)]
     L.cray_film_unpack.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
     L.cray_host_scene_flat.restype = C.POINTER(FlatScene)
@@ -467,6 +471,20 @@ def set_sobol_vectors(table):
     t = np.ascontiguousarray(table, dtype=np.uint16)
     assert t.shape == (64, 16, 4)
     _check(lib().cray_set_sobol_vectors(t.ctypes.data), 'cray_set_sobol_vectors')
+
+
+def preview_checkerboard(width, height, tile=(64, 64)):
+    out = np.zeros((height, width), dtype=np.uint32)
+    lib().cray_preview_checkerboard(width, height, tile[0], tile[1], out.ctypes.data)
+    return out
+
+
+def preview_pixels(film, divisor=1.0):
+    """Film [H, W, 3] f32 -> the preview's 0x00RRGGBB pixels (craytracer.rs:190-205, Color::to_rgb)."""
+    f = np.ascontiguousarray(film, dtype=np.float32)
+    out = np.zeros(f.shape[:2], dtype=np.uint32)
+    lib().cray_preview_pixels(f.ctypes.data, out.size, divisor, out.ctypes.data)
+    return out
 
 
 def load_image(path):

@@ -1,4 +1,5 @@
 // cray_io.cpp — OpenEXR writer for the Film (include/cray_io.h; reference src/bin/craytracer.rs:366-370).
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -25,6 +26,23 @@ void attr(std::vector<uint8_t>& b, const char* name, const char* type, const std
 }
 
 }  // namespace
+
+// The preview buffer of `render` (craytracer.rs:69-93, 190-205), headless.
+extern "C" void cray_preview_checkerboard(uint32_t w, uint32_t h, uint32_t tw, uint32_t th, uint32_t* out) {
+    if (!out || tw == 0 || th == 0) return;
+    for (uint32_t y = 0; y < h; y++)
+        for (uint32_t x = 0; x < w; x++) out[(size_t)y * w + x] = ((x / tw) + (y / th)) % 2 == 0 ? 0x999999u : 0xaaaaaau;
+}
+extern "C" void cray_preview_pixels(const float* rgb, uint64_t n, double divisor, uint32_t* out) {
+    if (!rgb || !out) return;
+    auto ch = [&](float v) -> uint32_t {   // Color::to_rgb (color.rs:47-54) on (v as f64) / divisor
+        double c = pow((double)v / divisor, 1.0 / 2.2);
+        c = c < 0.0 ? 0.0 : (c > 1.0 ? 1.0 : c);            // f64::clamp; NaN stays NaN ...
+        const double s = c * 255.0;
+        return s != s ? 0u : (uint32_t)(uint8_t)s;           // ... and `NaN as u8` is 0
+    };
+    for (uint64_t i = 0; i < n; i++) out[i] = (ch(rgb[3 * i]) << 16) | (ch(rgb[3 * i + 1]) << 8) | ch(rgb[3 * i + 2]);
+}
 
 extern "C" int cray_write_exr(const char* path, uint32_t w, uint32_t h, const float* rgb) {
     if (!path || !rgb || w == 0 || h == 0 || w > (1u << 24) || h > (1u << 24)) { cray::set_last_error("cray_write_exr: bad argument"); return CRAY_ERR_INVALID; }

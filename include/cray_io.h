@@ -24,6 +24,15 @@ int cray_write_exr(const char* path, uint32_t width, uint32_t height, const floa
  * Call with rgb == NULL to get the size. */
 int cray_read_exr(const char* path, uint32_t* width, uint32_t* height, float* rgb, uint64_t capacity_floats);
 
+/* The preview buffer of `render` (src/bin/craytracer.rs:69-93, 190-205) without the window: what a host blits while a frame
+ * is in flight.  minifb's window itself (:45-66, 95-144) stays with the host.
+ *   cray_preview_checkerboard: the initial pattern, 0x999999 / 0xaaaaaa per tile (tile_x + tile_y even / odd), :78-91
+ *   cray_preview_pixels: pixel i = to_rgb(Color(rgb[3i..3i+3]) / divisor) packed 0x00RRGGBB (:192-204; Color::to_rgb,
+ *     src/color.rs:47-54: powf(1 / 2.2), clamp, * 255, `as u8`).  With the film cray_render returns for samples [0, s)
+ *     (already divided by num_samples) pass divisor = s / num_samples to get the running average the reference shows. */
+void cray_preview_checkerboard(uint32_t width, uint32_t height, uint32_t tile_width, uint32_t tile_height, uint32_t* out);
+void cray_preview_pixels(const float* rgb, uint64_t n_pixels, double divisor, uint32_t* out);
+
 /* Texture files for hosts without an image library — what the reference does with the `image` crate
  * (`image::io::Reader::open(path).decode()` + `.to_rgb8()`, src/obj.rs:16-24, src/texture.rs:57-58):
  *   PNM (P6 / P3 / P5 / P2), PNG (every colour type and bit depth, Adam7, own inflate; alpha dropped, 16-bit scaled by

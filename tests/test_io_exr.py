@@ -105,3 +105,21 @@ def test_damaged_files_are_errors_not_crashes(tmp_path):
     open(bad, 'wb').write(bytes(b))
     with pytest.raises(backend.CrayError):
         backend.read_exr(bad)
+
+
+def test_preview_buffer_follows_the_reference():
+    """cray_preview_pixels = Color::to_rgb (color.rs:47-54) of film / divisor packed 0x00RRGGBB (craytracer.rs:192-204), against
+    the oracle's restatement of to_rgb; cray_preview_checkerboard = the tile pattern of create_preview_buffer (:78-91)."""
+    from oracle import oracle_lib as ol
+    rng = np.random.default_rng(8)
+    film = np.concatenate([rng.uniform(0, 1.5, (6, 9, 3)), np.array([[[0.0, 1.0, 2.0], [-0.5, 1e-9, 0.5], [np.inf, np.nan, 0.2]] + [[0.1, 0.2, 0.3]] * 6])]).astype(np.float32)
+    for divisor in (1.0, 0.25):
+        got = backend.preview_pixels(film, divisor)
+        for (y, x), px in np.ndenumerate(got):
+            c = (film[y, x].astype(np.float64) / divisor)
+            want = np.zeros(3, dtype=np.uint8)
+            ol.lib().orc_color_to_rgb(np.ascontiguousarray(c).ctypes.data, want.ctypes.data)
+            assert px == (int(want[0]) << 16) | (int(want[1]) << 8) | int(want[2]), (y, x, c, hex(px), want)
+    cb = backend.preview_checkerboard(200, 130)
+    assert cb[0, 0] == 0x999999 and cb[0, 64] == 0xaaaaaa and cb[64, 0] == 0xaaaaaa and cb[64, 64] == 0x999999 and cb[129, 199] == 0xaaaaaa
+    assert set(np.unique(cb).tolist()) == {0x999999, 0xaaaaaa}
