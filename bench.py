@@ -91,6 +91,8 @@ def main():
     ap.add_argument('--cpu-baseline', type=int, default=1)
     ap.add_argument('--count-pass', type=int, default=1)
     ap.add_argument('--host-bvh', type=int, default=0, help='1: Bvh::new on the host, tree uploaded (default: resident build, Bvh::new inside the upload on the GPU)')
+    ap.add_argument('--precision', default='f64', choices=['f64', 'f32'],
+                    help="f32: the separately reported fast mode (f32 traversal, NOT bit-exact); the headline is f64")
     ap.add_argument('--replicate-host', type=int, default=0,
                     help='N > 1: 1 = every rank builds and uploads the scene itself instead of cray_scene_broadcast from rank 0')
     args = ap.parse_args()
@@ -146,6 +148,9 @@ def main():
         if rank == 0:
             log('scene broadcast to %d ranks: %.2f s' % (world, time.time() - tb))
     assert (dev.width, dev.height) == (W, H)
+    dev.precision = args.precision
+    if args.precision != 'f64':
+        args.count_pass = 0   # the traversal counters (and with them the algorithmic bytes) are defined by the f64 traversal
 
     # Film resident on the rank-0 host, like the Vec<f32> handed to on_render_finish (pinned, so the copy out of the
     # device is one asynchronous DMA)
@@ -274,7 +279,8 @@ def main():
             'metric': 'Mray/s (BVH queries actually traversed: Scene::intersect + Scene::intersects) on the %dx%dx%dspp %s frame' % (W, H, wl['spp'], 'dragon-class' if wl['scene'] == 'dragon' else wl['scene']),
             'value': round(value, 2), 'unit': 'Mray/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 2), 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
-            'dtype': 'f64', 'data': 'synthetic',
+            'dtype': 'f64' if args.precision == 'f64' else 'f32 traversal + f64 shading (fast mode: NOT the reference arithmetic, reported separately)',
+            'data': 'synthetic',
             'config': {'workload': '%s, %s triangles, %dx%d, %d spp, depth %d'
                                    % (wl['label'], n_tris, W, H, wl['spp'], wl['max_depth']),
                        'parallelism': ('tile-shard x%d; C ABI: cray_comm_init + %s + cray_render_gather (RCCL ncclSend/ncclRecv of Film tiles to rank 0)'
@@ -290,6 +296,17 @@ def main():
                                    'shade': round(kern[5] / args.steps, 2), 'other': round(kern[6] / args.steps, 2),
                                    'note': "rank 0's share" if world > 1 else 'whole frame'},
         }
+        if args.precision != 'f64' and world == 1:
+            # how far the fast film is from the exact one: both rendered here, RMSE over RGB (north star: < 1e-4 for the exact path)
+            exact = np.empty_like(host_np)
+            dev.precision = 'f64'
+            dev.render(seed=0, out=exact)
+            dev.precision = args.precision
+            fast = np.empty_like(host_np)
+            dev.render(seed=0, out=fast)
+            diff = fast.astype(np.float64) - exact.astype(np.float64)
+            line['fast_mode'] = {'rmse_vs_f64': float(np.sqrt(np.mean(diff ** 2))), 'mean_f64': float(exact.mean()), 'mean_fast': float(fast.mean()),
+                                 'pixels_differing': float((fast != exact).any(axis=2).mean())}
         if counts:
             line['traversal'] = {k: counts[k] for k in ('closest_rays', 'shadow_rays', 'shadow_skipped', 'closest_nodes', 'closest_prims', 'shadow_nodes', 'shadow_prims')}
         print(json.dumps(line), flush=True)

@@ -23,7 +23,8 @@ class RenderParams(C.Structure):
                 ('sample_batch', C.c_uint32), ('rank', C.c_uint32), ('world_size', C.c_uint32),
                 ('sample_begin', C.c_uint32), ('sample_end', C.c_uint32), ('out_is_device', C.c_uint32),
                 ('count_traversal', C.c_uint32), ('max_paths_in_flight', C.c_uint64),
-                ('integrator', C.c_uint32), ('sampler', C.c_uint32), ('uniform_nx', C.c_uint32), ('uniform_ny', C.c_uint32)]
+                ('integrator', C.c_uint32), ('sampler', C.c_uint32), ('uniform_nx', C.c_uint32), ('uniform_ny', C.c_uint32),
+                ('precision', C.c_uint32), ('pad_', C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -371,11 +372,14 @@ class DeviceScene:
     #: integrator 'path' | 'simple' (src/simple_integrator.rs), uniform_sampler None | (nx, ny) (sampling.rs:154-194)
     integrator = 'path'
     uniform_sampler = None
+    #: 'f64' (the reference's arithmetic) or 'f32' (fast mode: f32 traversal, NOT bit-exact; cray_render_params.precision)
+    precision = 'f64'
 
     def params(self, seed=0, rank=0, world_size=1, sample_range=None, count_traversal=False, max_paths_in_flight=0):
         p = RenderParams()
         lib().cray_render_params_default(C.byref(p))
         p.integrator = {'path': 0, 'simple': 1}[self.integrator]
+        p.precision = {'f64': 0, 'f32': 1}[self.precision]
         if self.uniform_sampler is not None:
             p.sampler, (p.uniform_nx, p.uniform_ny) = 1, self.uniform_sampler
         p.seed, p.rank, p.world_size = seed, rank, world_size

@@ -48,6 +48,20 @@ struct alignas(16) LeafSlot {
 };
 static_assert(sizeof(LeafSlot) == 80, "LeafSlot is five 16-B loads");
 
+// ---- "fast" mode (cray_render_params.precision = CRAY_PRECISION_F32_TRAVERSAL): the same tree, f32 records.
+// Bounds are rounded OUTWARD (lo down, hi up), so a box never shrinks; triangles are rounded to nearest.  NOT bit-exact with
+// the reference: reported separately.
+struct alignas(64) InnerNode32 {
+    float lo0[3], hi0[3], lo1[3], hi1[3];
+    uint32_t ref0, ref1, axis, pad_;
+};
+static_assert(sizeof(InnerNode32) == 64, "InnerNode32 is four 16-B loads");
+struct alignas(16) LeafSlot32 {
+    float v0[3], e1[3], e2[3];
+    uint32_t prim, kind, pad_;
+};
+static_assert(sizeof(LeafSlot32) == 48, "LeafSlot32 is three 16-B loads");
+
 struct TriShade {
     double n0[3], n01[3], n02[3];
     double uv0[2], uv01[2], uv02[2];
@@ -79,6 +93,8 @@ struct DevScene {
     uint32_t bounds_in_div_range, pad_div_;  // every node bound is 0 or within [2^-500, 2^500]: div_fast is exact
     const InnerNode* inner;
     const LeafSlot* slots;
+    const InnerNode32* inner32;   // fast mode only (built on first use)
+    const LeafSlot32* slots32;
     // primitives
     const cray_prim* prims;
     const TriShade* tri_shade;  // indexed by prims[].shape for triangles

@@ -56,6 +56,7 @@ struct cray_ctx {
     int n_cu = 256;
     unsigned int refill_min = 16;  // idle lanes a wave waits for before it fetches new rays
     int trace_blocks_per_cu = 4;
+    int trace32_blocks_per_cu = 4;
     int shade_blocks_per_cu = 4;
     // path-state pool
     size_t capacity = 0;
@@ -103,6 +104,8 @@ struct cray_scene {
     DevScene dev{};
     std::vector<void*> allocs;
     std::vector<size_t> alloc_bytes;  // parallel to allocs, in the order of scene_arrays()
+    std::vector<void*> extra_allocs;  // per-rank extras that are not part of a broadcast (the f32 records of the fast mode)
+    uint32_t n_slots = 0;             // leaf slots (without the pad slot)
     uint64_t bytes = 0;
     uint32_t n_prims = 0;
     cray_bvh_build_stats build_stats{};  // resident build only
@@ -296,6 +299,7 @@ extern "C" int cray_ctx_create(int device_id, void* stream, cray_ctx** out) {
     c->trace_blocks_per_cu = env_int("CRAY_TRACE_BLOCKS_PER_CU", 1, 16, c->trace_blocks_per_cu);
     c->shade_blocks_per_cu = env_int("CRAY_SHADE_BLOCKS_PER_CU", 1, 64, c->shade_blocks_per_cu);
     c->sort_shade = env_int("CRAY_SORT_SHADE", 0, 1, c->sort_shade);
+    c->trace32_blocks_per_cu = env_int("CRAY_TRACE32_BLOCKS_PER_CU", 1, 16, c->trace32_blocks_per_cu);
     *out = c;
     return CRAY_OK;
 }
@@ -320,6 +324,7 @@ extern "C" void cray_scene_free(cray_scene* s) {
     if (!s) return;
     if (s->ctx) (void)hipSetDevice(s->ctx->device);
     for (void* p : s->allocs) (void)hipFree(p);
+    for (void* p : s->extra_allocs) (void)hipFree(p);
     delete s;
 }
 extern "C" uint64_t cray_scene_device_bytes(const cray_scene* s) { return s ? s->bytes : 0; }
@@ -808,6 +813,7 @@ extern "C" int cray_scene_upload(cray_ctx* c, const cray_flat_scene* f, cray_sce
         feat |= sk == CRAY_SHAPE_TRIANGLE ? SF_HIT_TRI : (sk == CRAY_SHAPE_SPHERE ? SF_HIT_SPHERE : SF_HIT_DISK);
     }
     s->features = feat;
+    s->n_slots = f->n_prims;   // every primitive sits in exactly one leaf (Bvh::new partitions them)
     s->shade_variant = pick_shade_variant(feat);
     if (const char* ev = getenv("CRAY_SHADE_VARIANT")) {  // experiments: force an instantiation that still covers the scene
         const int v = atoi(ev);
@@ -840,6 +846,26 @@ std::vector<uint32_t> rank_pixels(uint32_t W, uint32_t H, const cray_render_para
             for (uint32_t x = tx; x < x1; x++) pix.push_back(y * W + x);
     }
     return pix;
+}
+
+// The f32 records of the fast mode, derived on the device from the f64 layout the first time a fast frame is asked for.
+int ensure_fast_layout(cray_ctx* c, cray_scene* s) {
+    if (s->dev.inner32) return CRAY_OK;
+    InnerNode32* i32 = nullptr;
+    LeafSlot32* s32 = nullptr;
+    const uint32_t n_inner = s->dev.n_inner ? s->dev.n_inner : 1u, n_slots = s->n_slots + 1u;
+    HIP_TRY(hipMalloc((void**)&i32, (size_t)n_inner * sizeof(InnerNode32)));
+    s->extra_allocs.push_back(i32);
+    HIP_TRY(hipMalloc((void**)&s32, ((size_t)n_slots + 1) * sizeof(LeafSlot32)));   // + one more: the 4-load fetch reads 16 B past a slot
+    s->extra_allocs.push_back(s32);
+    HIP_TRY(hipMemsetAsync(s32, 0, ((size_t)n_slots + 1) * sizeof(LeafSlot32), c->stream));
+    hipLaunchKernelGGL(k_make_inner32, dim3((n_inner + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, s->dev.inner, n_inner, i32);
+    hipLaunchKernelGGL(k_make_slots32, dim3((n_slots + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, s->dev.slots, n_slots, s32);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    s->bytes += (size_t)n_inner * sizeof(InnerNode32) + ((size_t)n_slots + 1) * sizeof(LeafSlot32);
+    s->dev.inner32 = i32; s->dev.slots32 = s32;
+    return CRAY_OK;
 }
 
 template <int I>
@@ -880,6 +906,7 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
     // k_shade(b) only, so they share ONE persistent launch (k_trace_mixed); with traversal counting (or the
     // material sort experiment) every query kind keeps its own launch so that the counters stay per kind.
     const bool mixed = !count && !c->sort_shade && c->mix_trace;
+    const bool fast = prm.precision == CRAY_PRECISION_F32_TRAVERSAL;   // check_render_args refuses it together with counting
     const unsigned int trace_all = prm.count_traversal == 1 ? 1u : 0u;  // 2 = count, but keep skipping zero-term shadow rays
     for (uint32_t b = 0; b < d.max_depth; b++) {
         const uint32_t* q = b == 0 ? nullptr : c->queue[b & 1];
@@ -889,11 +916,13 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
         // an upper bound of the live paths is not known on the host: size the grids for the pass
         const int g_trace = grid_for(c, n_paths, c->trace_blocks_per_cu);  // persistent: 4 blocks x 4 waves per CU at 4 waves/SIMD
         const int g_shade = grid_for(c, n_paths, c->shade_blocks_per_cu);
+        const int g_trace32 = grid_for(c, n_paths, c->trace32_blocks_per_cu);
 
         if (!mixed || b == 0) {
             HIP_TRY(hipMemsetAsync(&ctr->trace_head, 0, sizeof(unsigned int), st));
             if (tm) { int e = tm->begin(FAM_CLOSEST); if (e) return e; }
             if (count) hipLaunchKernelGGL((k_trace<false, true>), dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
+            else if (fast) hipLaunchKernelGGL((k_trace32<kTraceClosest>), dim3(g_trace32), dim3(kBlock), 0, st, d, c->ps, q, nq, n_paths, (const uint32_t*)nullptr, (const unsigned int*)nullptr, ctr, &ctr->trace_head, c->refill_min, b == 0 ? 1u : 0u);
             else hipLaunchKernelGGL((k_trace<false, false>), dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
             if (tm) { int e = tm->end(); if (e) return e; }
         }
@@ -916,12 +945,16 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
 
         if (mixed && b + 1 < d.max_depth) {
             if (tm) { int e = tm->begin(FAM_MIXED); if (e) return e; }
-            hipLaunchKernelGGL(k_trace_mixed, dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow,
+            if (fast) hipLaunchKernelGGL((k_trace32<kTraceMixed>), dim3(g_trace32), dim3(kBlock), 0, st, d, c->ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, 0u,
+                                         (const uint32_t*)q_next, (const unsigned int*)n_next, ctr, &ctr->trace_head, c->refill_min, 0u);
+            else hipLaunchKernelGGL(k_trace_mixed, dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow,
                                (const uint32_t*)q_next, (const unsigned int*)n_next, ctr, &ctr->trace_head, c->refill_min);
             if (tm) { int e = tm->end(); if (e) return e; }
         } else {
             if (tm) { int e = tm->begin(FAM_ANY); if (e) return e; }
             if (count) hipLaunchKernelGGL((k_trace<true, true>), dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, c->shadow_queue, &ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
+            else if (fast) hipLaunchKernelGGL((k_trace32<kTraceAny>), dim3(g_trace32), dim3(kBlock), 0, st, d, c->ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, 0u,
+                                              (const uint32_t*)nullptr, (const unsigned int*)nullptr, ctr, &ctr->trace_head, c->refill_min, 0u);
             else hipLaunchKernelGGL((k_trace<true, false>), dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, c->shadow_queue, &ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
             if (tm) { int e = tm->end(); if (e) return e; }
         }
@@ -943,6 +976,11 @@ int check_render_args(cray_ctx* c, cray_scene* s, const cray_render_params* p) {
     if (s->ctx != c) { set_last_error("scene was uploaded through a different context"); return CRAY_ERR_INVALID; }
     if (p->tile_width == 0 || p->tile_height == 0 || p->sample_batch == 0 || p->world_size == 0 || p->rank >= p->world_size) {
         set_last_error("cray_render: bad tile/batch/rank parameters");
+        return CRAY_ERR_INVALID;
+    }
+    if (p->precision > CRAY_PRECISION_F32_TRAVERSAL) { set_last_error("cray_render: unknown precision"); return CRAY_ERR_INVALID; }
+    if (p->precision == CRAY_PRECISION_F32_TRAVERSAL && p->count_traversal) {
+        set_last_error("cray_render: the traversal counters are defined by the reference's f64 traversal; not available in the f32 fast mode");
         return CRAY_ERR_INVALID;
     }
     if (p->integrator > CRAY_INTEGRATOR_SIMPLE || p->sampler > CRAY_SAMPLER_UNIFORM) { set_last_error("cray_render: unknown integrator / sampler"); return CRAY_ERR_INVALID; }
@@ -1032,6 +1070,7 @@ int render_local(cray_ctx* c, cray_scene* s, const cray_render_params* prm, cray
     if (s_end > d.num_samples) s_end = d.num_samples;
     int e;
     if ((e = ensure_pix_list(c, W, H, *prm))) return e;
+    if (prm->precision == CRAY_PRECISION_F32_TRAVERSAL && (e = ensure_fast_layout(c, s))) return e;
     const size_t n_pix_rank = c->pix_count;
     const size_t film_floats = (size_t)W * H * 3;
     if ((e = ensure_buffer(&c->film, &c->film_floats, film_floats))) return e;
@@ -1676,6 +1715,8 @@ extern "C" int cray_scene_broadcast(cray_ctx* c, cray_scene* mine, int root, cra
         s = new cray_scene();
         s->ctx = c; s->dev = h.dev; s->n_prims = h.n_prims;
         s->features = h.features; s->shade_variant = h.shade_variant;
+        s->n_slots = h.n_prims;
+        s->dev.inner32 = nullptr; s->dev.slots32 = nullptr;   // the fast-mode records are derived per rank on first use
         const void** fields[kSceneArrays];
         scene_arrays(s->dev, fields);
         for (int i = 0; i < kSceneArrays; i++) {

@@ -300,6 +300,249 @@ __global__ void __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace_mixed(DevSce
     trace_body<kTraceMixed, false>(sc, ps, any_queue, *n_any_ptr, closest_queue, *n_closest_ptr, nullptr, ctr, work_head, refill_min);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// "Fast" traversal: f32 node and triangle records (64-B / 48-B, four loads per visit instead of seven), f32 slab and
+// Moller-Trumbore arithmetic.  NOT the reference's arithmetic: hits near silhouettes and shadow-ray leaks fall differently,
+// so films differ from the f64 path by a small RMSE that shrinks with the sample count (reported separately).
+// Same tree, same traversal order and the same persistent per-lane state machine as trace_body.  Spheres and disks (the
+// r = 1e5 ground sphere cancels catastrophically in f32) are still tested in f64.  A ray never tests the triangle it starts
+// on (`skip`): f32 hit points lie ~1e-5 off their surface, which the reference's 1e-9 epsilon cannot absorb.
+// ---------------------------------------------------------------------------------------------------------------
+#ifndef CRAY_TRACE32_WAVES
+#define CRAY_TRACE32_WAVES 4
+#endif
+__device__ __forceinline__ float child_key32(const float* lo, const float* hi, const float o[3], const float rd[3], float t_lo) {
+    float tmin = -__builtin_huge_valf(), tmax = __builtin_huge_valf();
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float t0 = (lo[a] - o[a]) * rd[a], t1 = (hi[a] - o[a]) * rd[a];
+        tmin = fmaxf(tmin, fminf(t0, t1));   // fminf / fmaxf drop a NaN (0 * inf: origin on a slab of a parallel ray)
+        tmax = fminf(tmax, fmaxf(t0, t1));
+    }
+    tmax *= 1.0000004f;                      // 2 ulp: keep the test conservative under f32 rounding
+    return (tmin <= tmax && tmax > t_lo) ? tmin : __builtin_huge_valf();   // accepted iff key < ray.tmax
+}
+
+template <int MODE>
+__device__ __forceinline__ void trace_body32(const DevScene& sc, const PathState& ps, const uint32_t* __restrict__ queue, const uint32_t n_first,
+                                             const uint32_t* __restrict__ queue_b, const uint32_t n_b, Counters* ctr, unsigned int* work_head,
+                                             unsigned int refill_min, uint32_t first_bounce) {
+    const uint32_t n = n_first + n_b;
+    bool is_any = MODE == kTraceAny;
+#define CRAY_ANY_LANE (MODE == kTraceMixed ? is_any : (MODE == kTraceAny))
+    const unsigned int lane = __lane_id(), tid = threadIdx.x;
+    unsigned int overflow = 0;
+    __shared__ uint32_t lds_ref[kLdsStack * kBlock];
+    __shared__ float lds_key[kLdsStack * kBlock];
+    uint32_t sref[kStackDepth - kLdsStack];
+    float skey[kStackDepth - kLdsStack];
+    int sp = 0;
+    bool active = false, exhausted = false, pending = false;
+    unsigned int res_base = 0, res_left = 0;
+    unsigned int chunk = n / (gridDim.x * (kBlock / 64) * 4u);
+    chunk = chunk < 64u ? 64u : (chunk > 512u ? 512u : chunk);
+    uint32_t p = 0, cur = 0;
+    int32_t skip = -1;                  // the triangle this ray starts on
+    ray_t ray = mkray(mk(0, 0, 0), mk(0, 0, 1));   // f64 ray: spheres / disks, and the exact t of their hits
+    float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 1.f}, rd[3] = {0.f, 0.f, 1.f};
+    float tmax = 0.f, t_lo = 0.f;       // f32 view of ray.tmax, and the near limit (relative to the origin's magnitude)
+    double hit_t = 0.0, hit_u = 0.0, hit_v = 0.0;
+    int32_t hit_prim = -1;
+
+    for (;;) {
+        const unsigned long long idle = __ballot(!active);
+        const bool do_refill = (unsigned int)__popcll(idle) >= refill_min && !exhausted;
+        if ((do_refill || idle == ~0ull) && pending) {
+            if (CRAY_ANY_LANE) {
+                ps.lr[p] = ps.lr[p] + ps.cr[p];
+                ps.lg[p] = ps.lg[p] + ps.cg[p];
+                ps.lb[p] = ps.lb[p] + ps.cb[p];
+            } else {
+                ps.ht[p] = hit_t; ps.hu[p] = hit_u; ps.hv[p] = hit_v; ps.hprim[p] = hit_prim;
+            }
+            pending = false;
+        }
+        if (do_refill) {
+            if (res_left == 0) {
+                const unsigned int leader = __ffsll((long long)idle) - 1;
+                unsigned int base = 0;
+                if (lane == leader) base = atomicAdd(work_head, chunk);
+                base = __shfl(base, leader);
+                if (base >= n) { exhausted = true; }
+                else { res_base = base; res_left = n - base < chunk ? n - base : chunk; }
+            }
+            const unsigned int rank = (unsigned int)__popcll(idle & ((1ull << lane) - 1ull));
+            const bool take = !active && rank < res_left;
+            const unsigned int mine = res_base + rank;
+            const unsigned int taken = (unsigned int)__popcll(__ballot(take));
+            res_base += taken; res_left -= taken;
+            if (take) {
+                if (MODE == kTraceMixed) {
+                    is_any = mine < n_first;
+                    if (is_any) p = queue[mine];
+                    else p = queue_b ? queue_b[mine - n_first] : mine - n_first;
+                } else {
+                    p = queue ? queue[mine] : mine;
+                }
+                if (CRAY_ANY_LANE) {
+                    ray.o = mk(ps.sox[p], ps.soy[p], ps.soz[p]);
+                    ray.d = mk(ps.sdx[p], ps.sdy[p], ps.sdz[p]);
+                    ray.tmax = ps.stmax[p];
+                } else {
+                    ray.o = mk(ps.ox[p], ps.oy[p], ps.oz[p]);
+                    ray.d = mk(ps.dx[p], ps.dy[p], ps.dz[p]);
+                    ray.tmax = inf64();
+                }
+                skip = first_bounce ? -1 : ps.hprim[p];     // shadow rays and continued segments start on the last hit
+                o[0] = (float)ray.o.x; o[1] = (float)ray.o.y; o[2] = (float)ray.o.z;
+                d[0] = (float)ray.d.x; d[1] = (float)ray.d.y; d[2] = (float)ray.d.z;
+                rd[0] = 1.0f / d[0]; rd[1] = 1.0f / d[1]; rd[2] = 1.0f / d[2];
+                // a shadow ray ends 1e-9 before its light (light.rs:125-128): in f32 that margin must be relative
+                tmax = CRAY_ANY_LANE ? __double2float_rd(ray.tmax) * 0.99998f : __builtin_huge_valf();
+                t_lo = 1e-4f * fmaxf(1.0f, fmaxf(fabsf(o[0]), fmaxf(fabsf(o[1]), fabsf(o[2]))));
+                hit_t = 0.0; hit_u = 0.0; hit_v = 0.0; hit_prim = -1;
+                sp = 0;
+                float rlo[3] = {__double2float_rd(sc.root_lo[0]), __double2float_rd(sc.root_lo[1]), __double2float_rd(sc.root_lo[2])};
+                float rhi[3] = {__double2float_ru(sc.root_hi[0]), __double2float_ru(sc.root_hi[1]), __double2float_ru(sc.root_hi[2])};
+                if (child_key32(rlo, rhi, o, rd, 0.0f) < tmax) { cur = sc.root_ref; active = true; }
+                else pending = true;
+            }
+        }
+        if (!__any(active)) {
+            if (exhausted) break;
+            continue;
+        }
+        bool need_pop = false, finished = false, occluded = false;
+        // one record fetch per iteration: the interior node (64 B) or the first slot of the leaf (48 B), four 16-B loads
+        const bool at_leaf = ref_is_leaf(cur);
+        float4 r0, r1, r2, r3;
+        r0 = r1 = r2 = r3 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (active) {
+            const float4* rec = at_leaf ? reinterpret_cast<const float4*>(sc.slots32 + ref_leaf_first(cur))
+                                        : reinterpret_cast<const float4*>(sc.inner32 + cur);
+            r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3];
+        }
+        if (active && !at_leaf) {
+            const float lo0[3] = {r0.x, r0.y, r0.z}, hi0[3] = {r0.w, r1.x, r1.y};
+            const float lo1[3] = {r1.z, r1.w, r2.x}, hi1[3] = {r2.y, r2.z, r2.w};
+            const uint32_t ref0 = __float_as_uint(r3.x), ref1 = __float_as_uint(r3.y), axis = __float_as_uint(r3.z);
+            const float k0 = child_key32(lo0, hi0, o, rd, 0.0f), k1 = child_key32(lo1, hi1, o, rd, 0.0f);
+            const bool right_first = (axis == 0 ? d[0] : (axis == 1 ? d[1] : d[2])) < 0.0f;
+            const uint32_t near = right_first ? ref1 : ref0, far = right_first ? ref0 : ref1;
+            const float kn = right_first ? k1 : k0, kf = right_first ? k0 : k1;
+            const bool an = kn < tmax, af = kf < tmax;
+            if (an) {
+                if (af) {
+                    if (sp < kLdsStack) { lds_ref[sp * kBlock + tid] = far; lds_key[sp * kBlock + tid] = kf; sp++; }
+                    else if (sp < kStackDepth) { sref[sp - kLdsStack] = far; skey[sp - kLdsStack] = kf; sp++; }
+                    else overflow = 1;
+                }
+                cur = near;
+            } else if (af) {
+                cur = far;
+            } else {
+                need_pop = true;
+            }
+        } else if (active) {
+            const uint32_t first = ref_leaf_first(cur), count = ref_leaf_count(cur);
+            for (uint32_t k = 0; k < count; k++) {
+                if (k > 0) {
+                    const float4* rec = reinterpret_cast<const float4*>(sc.slots32 + first + k);
+                    r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
+                }
+                const uint32_t s_prim = __float_as_uint(r2.y), s_kind = __float_as_uint(r2.z);
+                if (s_kind == CRAY_SHAPE_TRIANGLE) {
+                    if ((int32_t)s_prim == skip) continue;
+                    // Moller-Trumbore as in shape.rs:216-262, in f32
+                    const float v0[3] = {r0.x, r0.y, r0.z}, e1[3] = {r0.w, r1.x, r1.y}, e2[3] = {r1.z, r1.w, r2.x};
+                    const float P[3] = {d[1] * e2[2] - d[2] * e2[1], d[2] * e2[0] - d[0] * e2[2], d[0] * e2[1] - d[1] * e2[0]};
+                    const float det = P[0] * e1[0] + P[1] * e1[1] + P[2] * e1[2];
+                    if (det == 0.0f) continue;
+                    const float inv = 1.0f / det;
+                    const float T[3] = {o[0] - v0[0], o[1] - v0[1], o[2] - v0[2]};
+                    const float u = (P[0] * T[0] + P[1] * T[1] + P[2] * T[2]) * inv;
+                    if (!(u >= 0.0f && u <= 1.0f)) continue;
+                    const float Q[3] = {T[1] * e1[2] - T[2] * e1[1], T[2] * e1[0] - T[0] * e1[2], T[0] * e1[1] - T[1] * e1[0]};
+                    const float v = (Q[0] * d[0] + Q[1] * d[1] + Q[2] * d[2]) * inv;
+                    if (!(v >= 0.0f && u + v <= 1.0f)) continue;
+                    const float t = (Q[0] * e2[0] + Q[1] * e2[1] + Q[2] * e2[2]) * inv;
+                    if (t > t_lo && t < tmax) {
+                        if (CRAY_ANY_LANE) { occluded = true; break; }
+                        tmax = t; ray.tmax = (double)t;
+                        hit_t = (double)t; hit_u = (double)u; hit_v = (double)v; hit_prim = (int32_t)s_prim;
+                    }
+                } else {
+                    const cray_prim& pr = sc.prims[s_prim];
+                    const bool hit = s_kind == CRAY_SHAPE_SPHERE ? sphere_hit(sc.spheres[pr.shape], ray, CRAY_ANY_LANE, nullptr)
+                                                                 : disk_hit(sc.disks[pr.shape], ray, CRAY_ANY_LANE, nullptr);
+                    if (hit) {
+                        if (CRAY_ANY_LANE) { occluded = true; break; }
+                        hit_t = ray.tmax; hit_prim = (int32_t)s_prim;
+                        tmax = __double2float_ru(ray.tmax);
+                    }
+                }
+            }
+            if (CRAY_ANY_LANE && occluded) finished = true; else need_pop = true;
+        }
+        if (active && need_pop) {
+            for (;;) {
+                if (sp == 0) { finished = true; break; }
+                --sp;
+                float key;
+                uint32_t ref;
+                if (sp < kLdsStack) { key = lds_key[sp * kBlock + tid]; ref = lds_ref[sp * kBlock + tid]; }
+                else { key = skey[sp - kLdsStack]; ref = sref[sp - kLdsStack]; }
+                if (key < tmax) { cur = ref; break; }
+            }
+        }
+        if (active && finished) {
+            pending = CRAY_ANY_LANE ? !occluded : true;
+            active = false;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (MODE == kTraceMixed) {
+            atomicAdd(&ctr->shadow_rays, (unsigned long long)n_first);
+            atomicAdd(&ctr->closest_rays, (unsigned long long)n_b);
+        } else {
+            atomicAdd(MODE == kTraceAny ? &ctr->shadow_rays : &ctr->closest_rays, (unsigned long long)n);
+        }
+    }
+    if (overflow) atomicAdd(&ctr->stack_overflow, 1ull);
+#undef CRAY_ANY_LANE
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(kBlock, CRAY_TRACE32_WAVES) k_trace32(DevScene sc, PathState ps, const uint32_t* __restrict__ queue_a, const unsigned int* __restrict__ n_a_ptr,
+                                                                        uint32_t n_a_fixed, const uint32_t* __restrict__ queue_b, const unsigned int* __restrict__ n_b_ptr,
+                                                                        Counters* ctr, unsigned int* work_head, unsigned int refill_min, uint32_t first_bounce) {
+    const uint32_t n_a = n_a_ptr ? *n_a_ptr : n_a_fixed;
+    trace_body32<MODE>(sc, ps, queue_a, n_a, queue_b, (MODE == kTraceMixed && n_b_ptr) ? *n_b_ptr : 0u, ctr, work_head, refill_min, first_bounce);
+}
+
+// f64 device layout -> the f32 records of the fast mode (bounds rounded outward, triangles to nearest)
+__global__ void __launch_bounds__(kBlock) k_make_inner32(const InnerNode* __restrict__ in, uint32_t n, InnerNode32* __restrict__ out) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const InnerNode a = in[i];
+    InnerNode32 o;
+    for (int k = 0; k < 3; k++) {
+        o.lo0[k] = __double2float_rd(a.lo0[k]); o.hi0[k] = __double2float_ru(a.hi0[k]);
+        o.lo1[k] = __double2float_rd(a.lo1[k]); o.hi1[k] = __double2float_ru(a.hi1[k]);
+    }
+    o.ref0 = a.ref0; o.ref1 = a.ref1; o.axis = a.axis; o.pad_ = 0;
+    out[i] = o;
+}
+__global__ void __launch_bounds__(kBlock) k_make_slots32(const LeafSlot* __restrict__ in, uint32_t n, LeafSlot32* __restrict__ out) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const LeafSlot a = in[i];
+    LeafSlot32 o;
+    for (int k = 0; k < 3; k++) { o.v0[k] = (float)a.v0[k]; o.e1[k] = (float)a.e1[k]; o.e2[k] = (float)a.e2[k]; }
+    o.prim = a.prim; o.kind = a.kind; o.pad_ = 0;
+    out[i] = o;
+}
+
 // render_pixel up to the camera ray (craytracer.rs:148-156) for every path of a pass.
 // path p -> pixel pix_list[px0 + p / spp_pass], sample s_lo + p % spp_pass.  (Sample-major order was
 // measured: k_film gets trivially coalesced, but the traversal and k_shade lose the coherence of the 16

@@ -118,7 +118,13 @@ typedef struct {
     uint32_t integrator;        /* CRAY_INTEGRATOR_PATH (default) | CRAY_INTEGRATOR_SIMPLE */
     uint32_t sampler;           /* CRAY_SAMPLER_SOBOL (default) | CRAY_SAMPLER_UNIFORM */
     uint32_t uniform_nx, uniform_ny;
+    /* CRAY_PRECISION_F64 (default): the reference's arithmetic, results identical to it.
+     * CRAY_PRECISION_F32_TRAVERSAL: the "fast" mode of SURVEY.md §8(b) — the same tree traversed with f32 node / triangle
+     * records and f32 slab / triangle tests (shading stays f64).  NOT bit-exact: films differ from the f64 path by a small
+     * RMSE that shrinks with the sample count; reported separately, never the headline. */
+    uint32_t precision, pad_;
 } cray_render_params;
+enum { CRAY_PRECISION_F64 = 0, CRAY_PRECISION_F32_TRAVERSAL = 1 };
 enum { CRAY_INTEGRATOR_PATH = 0, CRAY_INTEGRATOR_SIMPLE = 1 };
 enum { CRAY_SAMPLER_SOBOL = 0, CRAY_SAMPLER_UNIFORM = 1 };
 
