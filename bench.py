@@ -93,6 +93,7 @@ def main():
     ap.add_argument('--host-bvh', type=int, default=0, help='1: Bvh::new on the host, tree uploaded (default: resident build, Bvh::new inside the upload on the GPU)')
     ap.add_argument('--precision', default='f64', choices=['f64', 'f32'],
                     help="f32: the separately reported fast mode (f32 traversal, NOT bit-exact); the headline is f64")
+    ap.add_argument('--max-paths', type=int, default=0, help='paths in flight per pass (0 = library default, 32 Mi)')
     ap.add_argument('--replicate-host', type=int, default=0,
                     help='N > 1: 1 = every rank builds and uploads the scene itself instead of cray_scene_broadcast from rank 0')
     args = ap.parse_args()
@@ -159,9 +160,9 @@ def main():
 
     def frame():
         if world > 1:
-            _, st = dev.render_gather(seed=0, out=host_np)
+            _, st = dev.render_gather(seed=0, out=host_np, max_paths_in_flight=args.max_paths)
         else:
-            _, st = dev.render(seed=0, out=host_np)
+            _, st = dev.render(seed=0, out=host_np, max_paths_in_flight=args.max_paths)
         return st
 
     def barrier():
@@ -215,7 +216,10 @@ def main():
         if os.path.exists(tpath) and world == 1:
             try:
                 ent = json.load(open(tpath)).get(args.workload, {})
-                traffic = ent.get('trace_bytes_per_launch')
+                # per launch of THIS run: the profiled frame's traversal traffic over this run's launches per frame (the pass
+                # plan, hence the number of launches, depends on the path pool; the bytes per frame do not)
+                per_frame = ent.get('trace_bytes_per_frame') or (ent.get('trace_bytes_per_launch', 0) * ent.get('trace_launches', 0))
+                traffic = round(per_frame / max(1.0, launches_per_frame)) if per_frame else None
                 provenance = {'file': 'profiles/hbm_traffic.json', 'pmc_csv': ent.get('source'), 'profiled_build': ent.get('git'),
                               'method': 'FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 from separate rocprofv3 --pmc passes (tools/traffic_from_pmc.py)'}
             except Exception:

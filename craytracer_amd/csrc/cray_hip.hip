@@ -1074,12 +1074,28 @@ int render_local(cray_ctx* c, cray_scene* s, const cray_render_params* prm, cray
     const size_t n_pix_rank = c->pix_count;
     const size_t film_floats = (size_t)W * H * 3;
     if ((e = ensure_buffer(&c->film, &c->film_floats, film_floats))) return e;
-    size_t capacity = prm->max_paths_in_flight ? (size_t)prm->max_paths_in_flight : ((size_t)32 << 20);
+    // Paths in flight per pass.  Fewer, larger passes are faster (every launch of a pass ends in a drain phase, and late bounces
+    // fill the chip better with more paths): configs[2] 295 ms at 32 Mi paths, 278 at 64 Mi, 267 with the whole frame (132.7 M
+    // paths, 31 GB of state) in one pass; configs[3] 1 468 -> 1 340 ms.  HBM is there to be used: by default the pool may take
+    // up to 45 % of the memory that is free (or already held by this pool), 232 B per path.
+    size_t capacity = (size_t)prm->max_paths_in_flight;
+    if (!capacity) {
+        size_t free_b = 0, total_b = 0;
+        constexpr size_t kBytesPerPath = 26 * 8 + 6 * 4;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+        capacity = (size_t)(0.45 * (double)(free_b + c->capacity * kBytesPerPath) / (double)kBytesPerPath);
+        if (capacity < ((size_t)32 << 20)) capacity = (size_t)32 << 20;
+    }
     const size_t need = n_pix_rank * (s_end > s_begin ? s_end - s_begin : 0);
     if (need < capacity) capacity = need;
     if (capacity < prm->sample_batch) capacity = prm->sample_batch;
     if (capacity >= ((size_t)1 << 32)) capacity = ((size_t)1 << 32) - 1;
-    if ((e = ensure_state(c, capacity))) return e;
+    while ((e = ensure_state(c, capacity))) {
+        // the adaptive default asked for more than the allocator gives (fragmentation, another tenant): halve and retry
+        if (prm->max_paths_in_flight || capacity <= ((size_t)32 << 20)) return e;
+        (void)hipGetLastError();
+        capacity /= 2;
+    }
     const std::vector<PassPlan> passes = plan(c->capacity, (uint32_t)n_pix_rank, s_begin, s_end, prm->sample_batch);
 
     for (int attempt = 0;; attempt++) {
