@@ -54,7 +54,9 @@ struct cray_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int n_cu = 256;
-    unsigned int refill_min = 16;  // idle lanes a wave waits for before it fetches new rays
+    // idle lanes a wave waits for before it fetches new rays: the coherent camera rays of bounce 0 finish together (late refills
+    // cost little and keep neighbouring pixels in one wave), the incoherent later bounces refill earlier (profiles/r02_experiments.md)
+    unsigned int refill_min = 28, refill_min_b0 = 64;
     int trace_blocks_per_cu = 4;
     int trace32_blocks_per_cu = 4;
     int shade_blocks_per_cu = 4;
@@ -296,6 +298,7 @@ extern "C" int cray_ctx_create(int device_id, void* stream, cray_ctx** out) {
     };
     c->mix_trace = env_int("CRAY_MIX_TRACE", 0, 1, c->mix_trace);
     c->refill_min = (unsigned int)env_int("CRAY_REFILL_MIN", 1, 64, (int)c->refill_min);
+    c->refill_min_b0 = (unsigned int)env_int("CRAY_REFILL_MIN_B0", 1, 64, (int)c->refill_min_b0);
     c->trace_blocks_per_cu = env_int("CRAY_TRACE_BLOCKS_PER_CU", 1, 16, c->trace_blocks_per_cu);
     c->shade_blocks_per_cu = env_int("CRAY_SHADE_BLOCKS_PER_CU", 1, 64, c->shade_blocks_per_cu);
     c->sort_shade = env_int("CRAY_SORT_SHADE", 0, 1, c->sort_shade);
@@ -923,7 +926,7 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
             if (tm) { int e = tm->begin(FAM_CLOSEST); if (e) return e; }
             if (count) hipLaunchKernelGGL((k_trace<false, true>), dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
             else if (fast) hipLaunchKernelGGL((k_trace32<kTraceClosest>), dim3(g_trace32), dim3(kBlock), 0, st, d, c->ps, q, nq, n_paths, (const uint32_t*)nullptr, (const unsigned int*)nullptr, ctr, &ctr->trace_head, c->refill_min, b == 0 ? 1u : 0u);
-            else hipLaunchKernelGGL((k_trace<false, false>), dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
+            else hipLaunchKernelGGL((k_trace<false, false>), dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, b == 0 ? c->refill_min_b0 : c->refill_min);
             if (tm) { int e = tm->end(); if (e) return e; }
         }
 
