@@ -40,8 +40,8 @@ constexpr int kBlock = 256;
 #ifndef CRAY_TRACE_WAVES
 #define CRAY_TRACE_WAVES 4
 #endif
-//  MODE 2 (mixed): ONE launch traces the shadow rays of bounce b (positions [0, n_any) of a virtual queue) and
-//  the path segments of bounce b+1 (the rest).  The two depend only on k_shade of bounce b, not on each other
+//  MODE 2 (mixed): ONE launch traces the path segments of bounce b+1 (positions [0, n_closest) of a virtual queue) and
+//  the shadow rays of bounce b (the rest).  The two depend only on k_shade of bounce b, not on each other
 //  (the shadow rays add to L, the segments write hit records), and together they have one drain phase instead
 //  of two — the lanes of a draining any-hit launch were 84 % idle for a fifth of its iterations.
 enum { kTraceClosest = 0, kTraceAny = 1, kTraceMixed = 2 };
@@ -81,8 +81,11 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
     bool active = false, exhausted = false;
     bool pending = false;  // ray finished, result still in registers (written at the next refill)
     unsigned int res_base = 0, res_left = 0;  // wave-uniform reserve of queue positions
+#ifndef CRAY_CHUNK_MAX
+#define CRAY_CHUNK_MAX 512u
+#endif
     unsigned int chunk = n / (gridDim.x * (kBlock / 64) * 4u);
-    chunk = chunk < 64u ? 64u : (chunk > 512u ? 512u : chunk);
+    chunk = chunk < 64u ? 64u : (chunk > CRAY_CHUNK_MAX ? CRAY_CHUNK_MAX : chunk);
     uint32_t p = 0, cur = 0;
     ray_t ray = mkray(mk(0, 0, 0), mk(0, 0, 1));
     vec3 rd = mk(0, 0, 1);   // 1 / ray.d per axis (exact-division helper)
@@ -127,9 +130,11 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
             res_base += taken; res_left -= taken;
             if (take) {
                 if (MODE == kTraceMixed) {
-                    is_any = mine < n_first;
-                    if (is_any) p = queue[mine];
-                    else p = queue_b ? queue_b[mine - n_first] : mine - n_first;
+                    // virtual queue: the path segments (long jobs: ~56 nodes per ray) first, the shadow rays (~43) last, so that
+                    // the launch drains on short jobs
+                    is_any = mine >= n_b;
+                    if (is_any) p = queue[mine - n_b];
+                    else p = queue_b ? queue_b[mine] : mine;
                 } else {
                     p = queue ? queue[mine] : mine;
                 }
