@@ -85,8 +85,8 @@ def exchange_comm_id(backend, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=2)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default='dragon', choices=sorted(WORKLOADS))
     ap.add_argument('--cpu-baseline', type=int, default=1)
     ap.add_argument('--count-pass', type=int, default=1)
