@@ -383,9 +383,9 @@ __device__ __forceinline__ void trace_body32(const DevScene& sc, const PathState
             res_base += taken; res_left -= taken;
             if (take) {
                 if (MODE == kTraceMixed) {
-                    is_any = mine < n_first;
-                    if (is_any) p = queue[mine];
-                    else p = queue_b ? queue_b[mine - n_first] : mine - n_first;
+                    is_any = mine >= n_b;   // path segments first, shadow rays last (as in trace_body)
+                    if (is_any) p = queue[mine - n_b];
+                    else p = queue_b ? queue_b[mine] : mine;
                 } else {
                     p = queue ? queue[mine] : mine;
                 }
