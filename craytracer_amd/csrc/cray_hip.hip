@@ -816,7 +816,7 @@ extern "C" int cray_scene_upload(cray_ctx* c, const cray_flat_scene* f, cray_sce
         feat |= sk == CRAY_SHAPE_TRIANGLE ? SF_HIT_TRI : (sk == CRAY_SHAPE_SPHERE ? SF_HIT_SPHERE : SF_HIT_DISK);
     }
     s->features = feat;
-    s->n_slots = f->n_prims;   // every primitive sits in exactly one leaf (Bvh::new partitions them)
+    s->n_slots = resident ? f->n_prims : f->n_prim_refs;   // every primitive sits in exactly one leaf (Bvh::new partitions them)
     s->shade_variant = pick_shade_variant(feat);
     if (const char* ev = getenv("CRAY_SHADE_VARIANT")) {  // experiments: force an instantiation that still covers the scene
         const int v = atoi(ev);
@@ -1603,6 +1603,7 @@ struct SceneHeader {
     uint64_t bytes[kSceneArrays];
     uint32_t n_prims, magic, features;
     int32_t shade_variant;
+    uint32_t n_slots, pad_;
 };
 
 }  // namespace
@@ -1721,7 +1722,7 @@ extern "C" int cray_scene_broadcast(cray_ctx* c, cray_scene* mine, int root, cra
     memset(&h, 0, sizeof(h));
     if (mine) {
         h.dev = mine->dev; h.n_prims = mine->n_prims; h.magic = 0x43524159u;
-        h.features = mine->features; h.shade_variant = mine->shade_variant;
+        h.features = mine->features; h.shade_variant = mine->shade_variant; h.n_slots = mine->n_slots;
         for (int i = 0; i < kSceneArrays; i++) h.bytes[i] = mine->alloc_bytes[i];
         HIP_TRY(hipMemcpyAsync(c->comm_scratch, &h, sizeof(h), hipMemcpyHostToDevice, c->stream));
     }
@@ -1734,7 +1735,7 @@ extern "C" int cray_scene_broadcast(cray_ctx* c, cray_scene* mine, int root, cra
         s = new cray_scene();
         s->ctx = c; s->dev = h.dev; s->n_prims = h.n_prims;
         s->features = h.features; s->shade_variant = h.shade_variant;
-        s->n_slots = h.n_prims;
+        s->n_slots = h.n_slots;
         s->dev.inner32 = nullptr; s->dev.slots32 = nullptr;   // the fast-mode records are derived per rank on first use
         const void** fields[kSceneArrays];
         scene_arrays(s->dev, fields);
