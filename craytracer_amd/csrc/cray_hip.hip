@@ -56,7 +56,7 @@ struct cray_ctx {
     int n_cu = 256;
     // idle lanes a wave waits for before it fetches new rays: the coherent camera rays of bounce 0 finish together (late refills
     // cost little and keep neighbouring pixels in one wave), the incoherent later bounces refill earlier (profiles/r02_experiments.md)
-    unsigned int refill_min = 28, refill_min_b0 = 64;
+    unsigned int refill_min = 28, refill_min_b0 = 64, refill_min_any = 40;
     int trace_blocks_per_cu = 4;
     int trace32_blocks_per_cu = 4;
     int shade_blocks_per_cu = 4;
@@ -299,6 +299,7 @@ extern "C" int cray_ctx_create(int device_id, void* stream, cray_ctx** out) {
     c->mix_trace = env_int("CRAY_MIX_TRACE", 0, 1, c->mix_trace);
     c->refill_min = (unsigned int)env_int("CRAY_REFILL_MIN", 1, 64, (int)c->refill_min);
     c->refill_min_b0 = (unsigned int)env_int("CRAY_REFILL_MIN_B0", 1, 64, (int)c->refill_min_b0);
+    c->refill_min_any = (unsigned int)env_int("CRAY_REFILL_MIN_ANY", 1, 64, (int)c->refill_min_any);
     c->trace_blocks_per_cu = env_int("CRAY_TRACE_BLOCKS_PER_CU", 1, 16, c->trace_blocks_per_cu);
     c->shade_blocks_per_cu = env_int("CRAY_SHADE_BLOCKS_PER_CU", 1, 64, c->shade_blocks_per_cu);
     c->sort_shade = env_int("CRAY_SORT_SHADE", 0, 1, c->sort_shade);
@@ -951,14 +952,14 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
             if (fast) hipLaunchKernelGGL((k_trace32<kTraceMixed>), dim3(g_trace32), dim3(kBlock), 0, st, d, c->ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, 0u,
                                          (const uint32_t*)q_next, (const unsigned int*)n_next, ctr, &ctr->trace_head, c->refill_min, 0u);
             else hipLaunchKernelGGL(k_trace_mixed, dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow,
-                               (const uint32_t*)q_next, (const unsigned int*)n_next, ctr, &ctr->trace_head, c->refill_min);
+                               (const uint32_t*)q_next, (const unsigned int*)n_next, ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16));
             if (tm) { int e = tm->end(); if (e) return e; }
         } else {
             if (tm) { int e = tm->begin(FAM_ANY); if (e) return e; }
             if (count) hipLaunchKernelGGL((k_trace<true, true>), dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, c->shadow_queue, &ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
             else if (fast) hipLaunchKernelGGL((k_trace32<kTraceAny>), dim3(g_trace32), dim3(kBlock), 0, st, d, c->ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, 0u,
                                               (const uint32_t*)nullptr, (const unsigned int*)nullptr, ctr, &ctr->trace_head, c->refill_min, 0u);
-            else hipLaunchKernelGGL((k_trace<true, false>), dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, c->shadow_queue, &ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
+            else hipLaunchKernelGGL((k_trace<true, false>), dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, c->shadow_queue, &ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min_any);
             if (tm) { int e = tm->end(); if (e) return e; }
         }
     }
@@ -1268,7 +1269,7 @@ extern "C" int cray_trace(cray_ctx* c, cray_scene* s, const cray_ray* rays, size
         HIP_TRY(hipMemcpy(&ctr->n_shadow, &cnt, sizeof(cnt), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(&ctr->n_active[0], &cnt, sizeof(cnt), hipMemcpyHostToDevice));
         hipLaunchKernelGGL(k_trace_mixed, dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow,
-                           (const uint32_t*)nullptr, (const unsigned int*)&ctr->n_active[0], ctr, &ctr->trace_head, c->refill_min);
+                           (const uint32_t*)nullptr, (const unsigned int*)&ctr->n_active[0], ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16));
     } else if (mode == CRAY_TRACE_ANY) {
         hipLaunchKernelGGL((k_trace<true, true>), dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)nullptr, (const unsigned int*)nullptr, (uint32_t)n, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
     } else if (mode == CRAY_TRACE_ANY_TIMED) {

@@ -98,7 +98,10 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
         // positions with ONE atomic and hands them out over several refills, so that most refills do not
         // start with a device-wide atomic round trip.
         const unsigned long long idle = __ballot(!active);
-        const bool do_refill = (unsigned int)__popcll(idle) >= refill_min && !exhausted;
+        // the shadow-ray part of a mixed launch (pixel-ordered rays towards few lights) is more coherent than the path
+        // segments and takes a higher threshold (the high 16 bits of refill_min carry it)
+        const unsigned int refill_now = (MODE == kTraceMixed && res_base >= n_b) ? (refill_min >> 16) : (refill_min & 0xffffu);
+        const bool do_refill = (unsigned int)__popcll(idle) >= refill_now && !exhausted;
         // Results of finished rays stay in registers until the wave refills (or drains): the stores then
         // run once with many lanes instead of in almost every iteration with one or two.
         if ((do_refill || idle == ~0ull) && pending) {
