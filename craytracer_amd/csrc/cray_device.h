@@ -18,8 +18,7 @@ namespace cray {
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kNoRef = 0xffffffffu;
 constexpr int kStackDepth = 96;
-constexpr int kShadeClasses = 8;
-constexpr uint32_t kShadeTile = 2048;  // paths per block-level queue flush in k_shade (8 x 256)  // miss, area light, then material index (folded)
+constexpr uint32_t kShadeTile = 2048;  // paths per block-level queue flush in k_shade (8 x 256)
 #ifndef CRAY_LDS_STACK
 #define CRAY_LDS_STACK 12
 #endif
@@ -135,7 +134,6 @@ struct Counters {
     unsigned long long closest_tri, shadow_tri;
     unsigned long long nonfinite, stack_overflow, shadow_skipped, closest_hits;
     unsigned int n_active[2], n_shadow, trace_head;
-    unsigned int n_class[kShadeClasses];
     unsigned long long diag[16];  // k_trace lane-occupancy diagnostics (CRAY_TRACE_DIAG builds only)
     // Third level of the traversal stack (LDS -> scratch -> here): entries kStackDepth.. of every lane, in global
     // memory as [entry][global thread].  Allocated by the runtime only after a frame overflowed the first two levels.

@@ -66,8 +66,6 @@ struct cray_ctx {
     PathState ps{};
     uint32_t* queue[2] = {nullptr, nullptr};
     uint32_t* shadow_queue = nullptr;
-    uint32_t* class_queues = nullptr;  // kShadeClasses x capacity (material sort)
-    int sort_shade = 0;
     // third stack level (Counters::deep_*), allocated after a frame overflowed LDS + scratch
     uint32_t* deep_ref = nullptr;
     double* deep_key = nullptr;
@@ -157,7 +155,6 @@ int ensure_state(cray_ctx* c, size_t capacity) {
     if ((r = alloc(capacity * 4, (void**)&c->queue[0]))) return r;
     if ((r = alloc(capacity * 4, (void**)&c->queue[1]))) return r;
     if ((r = alloc(capacity * 4, (void**)&c->shadow_queue))) return r;
-    if (c->sort_shade && (r = alloc(capacity * 4 * kShadeClasses, (void**)&c->class_queues))) return r;
     c->capacity = capacity;
     return CRAY_OK;
 }
@@ -302,7 +299,6 @@ extern "C" int cray_ctx_create(int device_id, void* stream, cray_ctx** out) {
     c->refill_min_any = (unsigned int)env_int("CRAY_REFILL_MIN_ANY", 1, 64, (int)c->refill_min_any);
     c->trace_blocks_per_cu = env_int("CRAY_TRACE_BLOCKS_PER_CU", 1, 16, c->trace_blocks_per_cu);
     c->shade_blocks_per_cu = env_int("CRAY_SHADE_BLOCKS_PER_CU", 1, 64, c->shade_blocks_per_cu);
-    c->sort_shade = env_int("CRAY_SORT_SHADE", 0, 1, c->sort_shade);
     c->trace32_blocks_per_cu = env_int("CRAY_TRACE32_BLOCKS_PER_CU", 1, 16, c->trace32_blocks_per_cu);
     *out = c;
     return CRAY_OK;
@@ -907,9 +903,9 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
     if (tm) { int e = tm->end(); if (e) return e; }
 
     // Launch sequence of a pass.  The shadow rays of bounce b and the path segments of bounce b+1 both depend on
-    // k_shade(b) only, so they share ONE persistent launch (k_trace_mixed); with traversal counting (or the
-    // material sort experiment) every query kind keeps its own launch so that the counters stay per kind.
-    const bool mixed = !count && !c->sort_shade && c->mix_trace;
+    // k_shade(b) only, so they share ONE persistent launch (k_trace_mixed); with traversal counting every query
+    // kind keeps its own launch so that the counters stay per kind.
+    const bool mixed = !count && c->mix_trace;
     const bool fast = prm.precision == CRAY_PRECISION_F32_TRAVERSAL;   // check_render_args refuses it together with counting
     const unsigned int trace_all = prm.count_traversal == 1 ? 1u : 0u;  // 2 = count, but keep skipping zero-term shadow rays
     for (uint32_t b = 0; b < d.max_depth; b++) {
@@ -934,17 +930,9 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
         HIP_TRY(hipMemsetAsync(n_next, 0, sizeof(unsigned int), st));
         HIP_TRY(hipMemsetAsync(&ctr->n_shadow, 0, sizeof(unsigned int), st));
         HIP_TRY(hipMemsetAsync(&ctr->trace_head, 0, sizeof(unsigned int), st));
-        if (c->sort_shade) HIP_TRY(hipMemsetAsync(ctr->n_class, 0, sizeof(unsigned int) * kShadeClasses, st));
         if (tm) { int e = tm->begin(FAM_SHADE); if (e) return e; }
-        if (c->sort_shade) {
-            hipLaunchKernelGGL(k_classify, dim3(grid_for(c, n_paths, 8)), dim3(kBlock), 0, st, d, c->ps, q, nq, n_paths, c->class_queues, c->capacity, ctr->n_class);
-            for (int cl = 0; cl < kShadeClasses; cl++)
-                ShadeLaunch<0>::go(s->shade_variant, mode, dim3(g_shade), st, d, c->ps, (const uint32_t*)(c->class_queues + (size_t)cl * c->capacity),
-                                   (const unsigned int*)&ctr->n_class[cl], 0u, b, spp_pass, pp.s_lo, q_next, n_next, c->shadow_queue, &ctr->n_shadow, ctr, trace_all, uni_nx, uni_ny);
-        } else {
-            ShadeLaunch<0>::go(s->shade_variant, mode, dim3(g_shade), st, d, c->ps, q, nq, n_paths, b, spp_pass, pp.s_lo, q_next, n_next,
-                               c->shadow_queue, &ctr->n_shadow, ctr, trace_all, uni_nx, uni_ny);
-        }
+        ShadeLaunch<0>::go(s->shade_variant, mode, dim3(g_shade), st, d, c->ps, q, nq, n_paths, b, spp_pass, pp.s_lo, q_next, n_next,
+                           c->shadow_queue, &ctr->n_shadow, ctr, trace_all, uni_nx, uni_ny);
         if (tm) { int e = tm->end(); if (e) return e; }
 
         if (mixed && b + 1 < d.max_depth) {

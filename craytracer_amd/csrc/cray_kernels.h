@@ -592,48 +592,9 @@ __device__ __forceinline__ void queue_push(uint32_t* __restrict__ q, unsigned in
     if (pred) q[base + __popcll(mask & ((1ull << lane) - 1ull))] = value;
 }
 
-// Material sort: split the live paths of a bounce into per-class queues (miss / emitter / material)
-// so that every k_shade launch runs one code path; a counting sort by wave ballots, one atomic per
-// wave and class.  MEASURED (profiles/r01_experiments.md): it makes k_shade 1.6-2x SLOWER on all three
-// configs (dragon 144 -> 234 ms, cornell 20.6 -> 41, staircase 640 -> 1326): shading is bound by
-// the path-state traffic (TCP pending-miss stalls, ~1000-cycle L2 read latency), and class queues
-// scatter the state accesses that the ascending compacted queue keeps nearly coalesced.  Kept
-// behind CRAY_SORT_SHADE=1 for later rounds (it only pays together with physical state compaction).
-__global__ void __launch_bounds__(kBlock) k_classify(DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
-                                                     const unsigned int* __restrict__ n_ptr, uint32_t n_fixed,
-                                                     uint32_t* __restrict__ class_queues, size_t class_stride, unsigned int* class_counts) {
-    const uint32_t n = n_ptr ? *n_ptr : n_fixed;
-    constexpr uint32_t kTile = 512;
-    __shared__ uint32_t lists[kShadeClasses][kTile];
-    __shared__ unsigned int cnt[kShadeClasses], base[kShadeClasses];
-    const uint32_t n_tiles = (n + kTile - 1) / kTile;
-    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        if (threadIdx.x < kShadeClasses) cnt[threadIdx.x] = 0;
-        __syncthreads();
-        for (uint32_t k = 0; k < kTile / kBlock; k++) {
-            const uint32_t i = tile * kTile + k * kBlock + threadIdx.x;
-            int cls = -1;
-            uint32_t p = 0;
-            if (i < n) {
-                p = queue ? queue[i] : i;
-                const int32_t hp = ps.hprim[p];
-                if (hp < 0) cls = 0;
-                else {
-                    const cray_prim pr = sc.prims[hp];
-                    cls = pr.light >= 0 ? 1 : 2 + (pr.material % (kShadeClasses - 2));
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < kShadeClasses; c++) queue_push(lists[c], &cnt[c], cls == c, p);
-        }
-        __syncthreads();
-        if (threadIdx.x < kShadeClasses) base[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(class_counts + threadIdx.x, cnt[threadIdx.x]) : 0u;
-        __syncthreads();
-        for (int c = 0; c < kShadeClasses; c++)
-            for (uint32_t j = threadIdx.x; j < cnt[c]; j += kBlock) class_queues[(size_t)c * class_stride + base[c] + j] = lists[c][j];
-        __syncthreads();
-    }
-}
+// (A material sort — per-class queues filled by a counting sort before k_shade — was measured in round 1 and made k_shade
+// 1.6-2x slower on all three configs: shading is bound by path-state traffic, which class queues scatter.  The code is gone;
+// profiles/r01_experiments.md has the numbers.)
 
 // The body of one estimate_Li iteration between the two BVH queries (path_integrator.rs:56-211).
 #ifndef CRAY_SHADE_WAVES
