@@ -117,10 +117,21 @@ def main():
     stream = torch.cuda.current_stream()
     ctx = backend.Context(local_rank, stream=stream.cuda_stream)
     store = None
-    if world > 1:
+    # CRAY_BENCH_FORCE_COMM=1: take the N > 1 code path (communicator, scene broadcast, cray_render_gather) with whatever
+    # world size there is — on a one-GPU box that rehearses everything but the ncclSend / ncclRecv transport itself
+    use_comm = world > 1 or os.environ.get('CRAY_BENCH_FORCE_COMM', '0') == '1'
+    if use_comm:
         cid, store = exchange_comm_id(backend, rank, world)
-        ctx.comm_init(cid, rank, world)   # ncclCommInitRank: one rank per GPU over RCCL / xGMI
-        ctx.barrier()
+        # RCCL prints a version banner to stdout on the first communicator: keep stdout for the ONE JSON line
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            ctx.comm_init(cid, rank, world)   # ncclCommInitRank: one rank per GPU over RCCL / xGMI
+            ctx.barrier()
+        finally:
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     wl = WORKLOADS[args.workload]
     W, H = wl['width'], wl['height']
@@ -143,7 +154,7 @@ def main():
                 % (len(scene.triangles), n_nodes, t1 - t0, t2 - t1, t3 - t2,
                    'Bvh::new on the host %.2fs' % host.bvh_seconds if args.host_bvh else 'incl. Bvh::new on the GPU, kernels %.3fs' % dev.build_stats['device_seconds'],
                    dev.device_bytes / 1e9))
-    if world > 1 and not args.replicate_host:
+    if use_comm and not args.replicate_host:
         tb = time.time()
         dev = ctx.broadcast_scene(dev, root=0)   # rank 0's HBM -> every rank's HBM over xGMI (C1)
         if rank == 0:
@@ -159,7 +170,7 @@ def main():
     host_np = host_film.numpy() if rank == 0 else None
 
     def frame():
-        if world > 1:
+        if use_comm:
             _, st = dev.render_gather(seed=0, out=host_np, max_paths_in_flight=args.max_paths)
         else:
             _, st = dev.render(seed=0, out=host_np, max_paths_in_flight=args.max_paths)
@@ -314,7 +325,7 @@ def main():
         if counts:
             line['traversal'] = {k: counts[k] for k in ('closest_rays', 'shadow_rays', 'shadow_skipped', 'closest_nodes', 'closest_prims', 'shadow_nodes', 'shadow_prims')}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_comm:
         ctx.barrier()
     dev.close()
     ctx.close()

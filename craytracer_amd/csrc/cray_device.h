@@ -18,7 +18,10 @@ namespace cray {
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kNoRef = 0xffffffffu;
 constexpr int kStackDepth = 96;
-constexpr uint32_t kShadeTile = 2048;  // paths per block-level queue flush in k_shade (8 x 256)
+#ifndef CRAY_SHADE_TILE
+#define CRAY_SHADE_TILE 2048
+#endif
+constexpr uint32_t kShadeTile = CRAY_SHADE_TILE;  // paths per block-level queue flush in k_shade (8 x 256)
 #ifndef CRAY_LDS_STACK
 #define CRAY_LDS_STACK 12
 #endif
