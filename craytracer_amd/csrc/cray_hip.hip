@@ -71,6 +71,7 @@ struct cray_ctx {
     double* deep_key = nullptr;
     unsigned int deep_depth = 0;
     size_t deep_threads = 0;
+    int hybrid = 1;     // certified f32 culling in the exact traversal (CRAY_HYBRID=0: f64 records only)
     int mix_trace = 1;  // shadow rays of bounce b and segments of bounce b+1 in one launch (CRAY_MIX_TRACE=0 disables)
     Counters* counters = nullptr;
     uint32_t* pix_list = nullptr;
@@ -111,6 +112,7 @@ struct cray_scene {
     cray_bvh_build_stats build_stats{};  // resident build only
     uint32_t features = SF_ALL;  // what the scene can make k_shade do (cray_shading.h)
     int shade_variant = kNumShadeVariants - 1;
+    bool hybrid_ok = false;  // the scene is inside the range the certified f32 culling is proven for (cray_math.h hyb_scene_ok)
 };
 
 namespace {
@@ -233,11 +235,13 @@ void fill_stats(const Counters& h, cray_stats* st) {
     st->nonfinite = h.nonfinite; st->stack_overflow = h.stack_overflow; st->closest_hits = h.closest_hits;
 #ifdef CRAY_TRACE_DIAG
     for (int a = 0; a < 2; a++) {
-        const unsigned long long* g = h.diag + 8 * a;
+        const unsigned long long* g = h.diag + 16 * a;
         if (!g[0]) continue;
-        fprintf(stderr, "diag %s: wave-iterations %llu, active lanes/iter %.1f (interior %.1f, leaf %.1f); exhausted iters %.1f%% at %.1f lanes; refills %llu x %.1f lanes\n",
-                a ? "any" : "closest", g[0], (double)g[1] / g[0], (double)g[6] / g[0], (double)g[7] / g[0], 100.0 * g[2] / g[0],
-                g[2] ? (double)g[3] / g[2] : 0.0, g[4], g[4] ? (double)g[5] / g[4] : 0.0);
+        fprintf(stderr, "diag %s: wave-iterations %llu, active lanes/iter %.1f (interior %.1f, leaf %.1f, resolve %.2f in %.1f%% of the iterations); exhausted iters %.1f%% at %.1f lanes; refills %llu x %.1f lanes\n",
+                a ? "any" : "closest", g[0], (double)g[1] / g[0], (double)g[6] / g[0], (double)g[7] / g[0], (double)g[8] / g[0], 100.0 * g[9] / g[0],
+                100.0 * g[2] / g[0], g[2] ? (double)g[3] / g[2] : 0.0, g[4], g[4] ? (double)g[5] / g[4] : 0.0);
+        fprintf(stderr, "diag %s: iterations with a lane at a leaf %.1f%%, at a sphere / disk slot %.1f%% (%.2f lanes), at a leaf of several slots %.1f%%\n",
+                a ? "any" : "closest", 100.0 * g[10] / g[0], 100.0 * g[11] / g[0], (double)g[13] / g[0], 100.0 * g[12] / g[0]);
     }
 #endif
 }
@@ -294,6 +298,7 @@ extern "C" int cray_ctx_create(int device_id, void* stream, cray_ctx** out) {
         return v < lo ? lo : (v > hi ? hi : v);
     };
     c->mix_trace = env_int("CRAY_MIX_TRACE", 0, 1, c->mix_trace);
+    c->hybrid = env_int("CRAY_HYBRID", 0, 1, c->hybrid);
     c->refill_min = (unsigned int)env_int("CRAY_REFILL_MIN", 1, 64, (int)c->refill_min);
     c->refill_min_b0 = (unsigned int)env_int("CRAY_REFILL_MIN_B0", 1, 64, (int)c->refill_min_b0);
     c->refill_min_any = (unsigned int)env_int("CRAY_REFILL_MIN_ANY", 1, 64, (int)c->refill_min_any);
@@ -848,23 +853,42 @@ std::vector<uint32_t> rank_pixels(uint32_t W, uint32_t H, const cray_render_para
     return pix;
 }
 
-// The f32 records of the fast mode, derived on the device from the f64 layout the first time a fast frame is asked for.
-int ensure_fast_layout(cray_ctx* c, cray_scene* s) {
+// The 64-B f32 interior records (bounds rounded outward), derived on the device from the f64 layout: read by the certified
+// f32 culling of the exact traversal (cray_math.h hyb_key) and by the fast mode.
+int ensure_inner32(cray_ctx* c, cray_scene* s) {
     if (s->dev.inner32) return CRAY_OK;
     InnerNode32* i32 = nullptr;
-    LeafSlot32* s32 = nullptr;
-    const uint32_t n_inner = s->dev.n_inner ? s->dev.n_inner : 1u, n_slots = s->n_slots + 1u;
-    HIP_TRY(hipMalloc((void**)&i32, (size_t)n_inner * sizeof(InnerNode32)));
+    const uint32_t n_inner = s->dev.n_inner ? s->dev.n_inner : 1u;
+    HIP_TRY(hipMalloc((void**)&i32, ((size_t)n_inner + 1) * sizeof(InnerNode32)));   // + one: the 5-load fetch of a hybrid lane never leaves the array
     s->extra_allocs.push_back(i32);
+    HIP_TRY(hipMemsetAsync(i32, 0, ((size_t)n_inner + 1) * sizeof(InnerNode32), c->stream));
+    hipLaunchKernelGGL(k_make_inner32, dim3((n_inner + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, s->dev.inner, n_inner, i32);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    s->bytes += ((size_t)n_inner + 1) * sizeof(InnerNode32);
+    s->dev.inner32 = i32;
+    return CRAY_OK;
+}
+// Exact traversal with certified f32 culling: decided per scene (range of the bounds), records derived on first use.
+int ensure_hybrid(cray_ctx* c, cray_scene* s) {
+    s->hybrid_ok = s->dev.bounds_in_div_range && hyb_scene_ok(s->dev.root_lo, s->dev.root_hi);
+    if (!c->hybrid || !s->hybrid_ok) return CRAY_OK;
+    return ensure_inner32(c, s);
+}
+// The f32 triangle records of the fast mode, derived the first time a fast frame is asked for.
+int ensure_fast_layout(cray_ctx* c, cray_scene* s) {
+    if (int e = ensure_inner32(c, s)) return e;
+    if (s->dev.slots32) return CRAY_OK;
+    LeafSlot32* s32 = nullptr;
+    const uint32_t n_slots = s->n_slots + 1u;
     HIP_TRY(hipMalloc((void**)&s32, ((size_t)n_slots + 1) * sizeof(LeafSlot32)));   // + one more: the 4-load fetch reads 16 B past a slot
     s->extra_allocs.push_back(s32);
     HIP_TRY(hipMemsetAsync(s32, 0, ((size_t)n_slots + 1) * sizeof(LeafSlot32), c->stream));
-    hipLaunchKernelGGL(k_make_inner32, dim3((n_inner + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, s->dev.inner, n_inner, i32);
     hipLaunchKernelGGL(k_make_slots32, dim3((n_slots + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, s->dev.slots, n_slots, s32);
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipGetLastError());
-    s->bytes += (size_t)n_inner * sizeof(InnerNode32) + ((size_t)n_slots + 1) * sizeof(LeafSlot32);
-    s->dev.inner32 = i32; s->dev.slots32 = s32;
+    s->bytes += ((size_t)n_slots + 1) * sizeof(LeafSlot32);
+    s->dev.slots32 = s32;
     return CRAY_OK;
 }
 
@@ -907,6 +931,12 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
     // kind keeps its own launch so that the counters stay per kind.
     const bool mixed = !count && c->mix_trace;
     const bool fast = prm.precision == CRAY_PRECISION_F32_TRAVERSAL;   // check_render_args refuses it together with counting
+    const bool hyb = s->dev.inner32 != nullptr && c->hybrid && s->hybrid_ok;   // certified f32 culling (cray_math.h hyb_key): same results
+#define CRAY_LAUNCH_TRACE(ANY_, COUNT_, ...)                                                                                   \
+    do {                                                                                                                        \
+        if (hyb) hipLaunchKernelGGL((k_trace<ANY_, COUNT_, true>), dim3(g_trace), dim3(kBlock), 0, st, __VA_ARGS__);              \
+        else hipLaunchKernelGGL((k_trace<ANY_, COUNT_, false>), dim3(g_trace), dim3(kBlock), 0, st, __VA_ARGS__);                 \
+    } while (0)
     const unsigned int trace_all = prm.count_traversal == 1 ? 1u : 0u;  // 2 = count, but keep skipping zero-term shadow rays
     for (uint32_t b = 0; b < d.max_depth; b++) {
         const uint32_t* q = b == 0 ? nullptr : c->queue[b & 1];
@@ -921,9 +951,9 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
         if (!mixed || b == 0) {
             HIP_TRY(hipMemsetAsync(&ctr->trace_head, 0, sizeof(unsigned int), st));
             if (tm) { int e = tm->begin(FAM_CLOSEST); if (e) return e; }
-            if (count) hipLaunchKernelGGL((k_trace<false, true>), dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
+            if (count) CRAY_LAUNCH_TRACE(false, true, d, c->ps, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
             else if (fast) hipLaunchKernelGGL((k_trace32<kTraceClosest>), dim3(g_trace32), dim3(kBlock), 0, st, d, c->ps, q, nq, n_paths, (const uint32_t*)nullptr, (const unsigned int*)nullptr, ctr, &ctr->trace_head, b == 0 ? c->refill_min_b0 : c->refill_min, b == 0 ? 1u : 0u);
-            else hipLaunchKernelGGL((k_trace<false, false>), dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, b == 0 ? c->refill_min_b0 : c->refill_min);
+            else CRAY_LAUNCH_TRACE(false, false, d, c->ps, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, b == 0 ? c->refill_min_b0 : c->refill_min);
             if (tm) { int e = tm->end(); if (e) return e; }
         }
 
@@ -939,15 +969,17 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
             if (tm) { int e = tm->begin(FAM_MIXED); if (e) return e; }
             if (fast) hipLaunchKernelGGL((k_trace32<kTraceMixed>), dim3(g_trace32), dim3(kBlock), 0, st, d, c->ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, 0u,
                                          (const uint32_t*)q_next, (const unsigned int*)n_next, ctr, &ctr->trace_head, c->refill_min, 0u);
-            else hipLaunchKernelGGL(k_trace_mixed, dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow,
+            else if (hyb) hipLaunchKernelGGL(k_trace_mixed<true>, dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow,
+                               (const uint32_t*)q_next, (const unsigned int*)n_next, ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16));
+            else hipLaunchKernelGGL(k_trace_mixed<false>, dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow,
                                (const uint32_t*)q_next, (const unsigned int*)n_next, ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16));
             if (tm) { int e = tm->end(); if (e) return e; }
         } else {
             if (tm) { int e = tm->begin(FAM_ANY); if (e) return e; }
-            if (count) hipLaunchKernelGGL((k_trace<true, true>), dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, c->shadow_queue, &ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
+            if (count) CRAY_LAUNCH_TRACE(true, true, d, c->ps, c->shadow_queue, &ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
             else if (fast) hipLaunchKernelGGL((k_trace32<kTraceAny>), dim3(g_trace32), dim3(kBlock), 0, st, d, c->ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, 0u,
                                               (const uint32_t*)nullptr, (const unsigned int*)nullptr, ctr, &ctr->trace_head, c->refill_min, 0u);
-            else hipLaunchKernelGGL((k_trace<true, false>), dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, c->shadow_queue, &ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min_any);
+            else CRAY_LAUNCH_TRACE(true, false, d, c->ps, c->shadow_queue, &ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min_any);
             if (tm) { int e = tm->end(); if (e) return e; }
         }
     }
@@ -959,6 +991,7 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
                            prm.sample_batch, c->film, ctr);
     }
     if (tm) { int e = tm->end(); if (e) return e; }
+#undef CRAY_LAUNCH_TRACE
     HIP_TRY(hipGetLastError());
     return CRAY_OK;
 }
@@ -1063,6 +1096,7 @@ int render_local(cray_ctx* c, cray_scene* s, const cray_render_params* prm, cray
     int e;
     if ((e = ensure_pix_list(c, W, H, *prm))) return e;
     if (prm->precision == CRAY_PRECISION_F32_TRAVERSAL && (e = ensure_fast_layout(c, s))) return e;
+    if ((e = ensure_hybrid(c, s))) return e;
     const size_t n_pix_rank = c->pix_count;
     const size_t film_floats = (size_t)W * H * 3;
     if ((e = ensure_buffer(&c->film, &c->film_floats, film_floats))) return e;
@@ -1247,6 +1281,8 @@ extern "C" int cray_trace(cray_ctx* c, cray_scene* s, const cray_ray* rays, size
     }
     const int g = grid_for(c, n, 8);
     Counters* ctr = c->counters;
+    if ((e = ensure_hybrid(c, s))) return e;
+    const bool hyb = s->dev.inner32 != nullptr && c->hybrid && s->hybrid_ok;
     if (mixed) {
         // k_trace_mixed as the frame loop launches it: positions [0, n) of the virtual queue are the shadow rays of paths
         // 0..n-1 (an identity queue), positions [n, 2n) the path segments of the same paths (tmax = +inf, like Ray::new)
@@ -1256,17 +1292,22 @@ extern "C" int cray_trace(cray_ctx* c, cray_scene* s, const cray_ray* rays, size
         HIP_TRY(hipMemcpy(c->shadow_queue, iota.data(), n * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(&ctr->n_shadow, &cnt, sizeof(cnt), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(&ctr->n_active[0], &cnt, sizeof(cnt), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_trace_mixed, dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow,
+        if (hyb) hipLaunchKernelGGL(k_trace_mixed<true>, dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow,
                            (const uint32_t*)nullptr, (const unsigned int*)&ctr->n_active[0], ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16));
-    } else if (mode == CRAY_TRACE_ANY) {
-        hipLaunchKernelGGL((k_trace<true, true>), dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)nullptr, (const unsigned int*)nullptr, (uint32_t)n, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
-    } else if (mode == CRAY_TRACE_ANY_TIMED) {
-        hipLaunchKernelGGL((k_trace<true, false>), dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)nullptr, (const unsigned int*)nullptr, (uint32_t)n, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
-    } else if (mode == CRAY_TRACE_CLOSEST) {
-        // closest hit with caller-supplied tmax: rays whose tmax is finite go through the same kernel via stmax
-        hipLaunchKernelGGL((k_trace<false, true>), dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)nullptr, (const unsigned int*)nullptr, (uint32_t)n, (const double*)ps.stmax, ctr, &ctr->trace_head, c->refill_min);
+        else hipLaunchKernelGGL(k_trace_mixed<false>, dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow,
+                           (const uint32_t*)nullptr, (const unsigned int*)&ctr->n_active[0], ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16));
     } else {
-        hipLaunchKernelGGL((k_trace<false, false>), dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)nullptr, (const unsigned int*)nullptr, (uint32_t)n, (const double*)ps.stmax, ctr, &ctr->trace_head, c->refill_min);
+#define CRAY_TRACE_GO(ANY_, COUNT_, TMAX_)                                                                                       \
+    do {                                                                                                                          \
+        if (hyb) hipLaunchKernelGGL((k_trace<ANY_, COUNT_, true>), dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)nullptr, (const unsigned int*)nullptr, (uint32_t)n, TMAX_, ctr, &ctr->trace_head, c->refill_min); \
+        else hipLaunchKernelGGL((k_trace<ANY_, COUNT_, false>), dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)nullptr, (const unsigned int*)nullptr, (uint32_t)n, TMAX_, ctr, &ctr->trace_head, c->refill_min); \
+    } while (0)
+        // closest hit with caller-supplied tmax: rays whose tmax is finite go through the same kernel via stmax
+        if (mode == CRAY_TRACE_ANY) CRAY_TRACE_GO(true, true, (const double*)nullptr);
+        else if (mode == CRAY_TRACE_ANY_TIMED) CRAY_TRACE_GO(true, false, (const double*)nullptr);
+        else if (mode == CRAY_TRACE_CLOSEST) CRAY_TRACE_GO(false, true, (const double*)ps.stmax);
+        else CRAY_TRACE_GO(false, false, (const double*)ps.stmax);
+#undef CRAY_TRACE_GO
     }
     cray_hit* closest_out = mixed ? hits + n : hits;
     if (do_any) {

@@ -601,3 +601,34 @@ extern "C" uint64_t cray_host_child_key_mismatches(const double* lo, const doubl
     if (n_checked) *n_checked = checked;
     return bad;
 }
+
+extern "C" uint64_t cray_host_hyb_key_violations(const double* lo, const double* hi, const double* o, const double* d, const double* tmax,
+                                                 uint64_t n, uint64_t* counts /* [4]: resolve, visit, cull, out-of-range rays */) {
+    using namespace cray;
+    uint64_t bad = 0, cnt[4] = {0, 0, 0, 0};
+    for (uint64_t i = 0; i < n; i++) {
+        const double *l = lo + 3 * i, *h = hi + 3 * i, *oo = o + 3 * i, *dd = d + 3 * i;
+        bool box_ok = hyb_scene_ok(l, h), fast = true;
+        for (int k = 0; k < 3; k++) {
+            box_ok = box_ok && l[k] <= h[k];
+            fast = fast && div_fast_ok(dd[k]) && div_range_ok(oo[k]) && div_range_ok(l[k]) && div_range_ok(h[k]);
+        }
+        if (!box_ok) continue;   // such a scene never runs the hybrid kernel
+        const vec3 ov = mk(oo[0], oo[1], oo[2]), dv = mk(dd[0], dd[1], dd[2]);
+        const vec3 rd = mk(1.0 / dd[0], 1.0 / dd[1], 1.0 / dd[2]);
+        const double key = child_key(l, h, ov, dv);   // the literal restatement of the reference
+        const HybRay hr = hyb_ray(ov, dv, rd, fast);
+        if (hr.a != hr.a) cnt[3]++;
+        float l32[3], h32[3];
+        for (int k = 0; k < 3; k++) { l32[k] = f32_down(l[k]); h32[k] = f32_up(h[k]); }
+        const float kc = hyb_key(l32, h32, hr);
+        float t_lo, t_hi;
+        hyb_tmax(tmax[i], t_lo, t_hi);
+        const int st = hyb_status(kc, hr.a, t_lo, t_hi);
+        cnt[st]++;
+        const bool accept = key < tmax[i];
+        if ((st == kHybVisit && !accept) || (st == kHybCull && accept)) bad++;
+    }
+    if (counts) for (int k = 0; k < 4; k++) counts[k] = cnt[k];
+    return bad;
+}

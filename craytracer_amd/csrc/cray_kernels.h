@@ -45,7 +45,9 @@ constexpr int kBlock = 256;
 //  (the shadow rays add to L, the segments write hit records), and together they have one drain phase instead
 //  of two — the lanes of a draining any-hit launch were 84 % idle for a fifth of its iterations.
 enum { kTraceClosest = 0, kTraceAny = 1, kTraceMixed = 2 };
-template <int MODE, bool COUNT>
+//  HYB        : certified f32 culling (cray_math.h hyb_key): interior nodes are read as 64-B f32 records, every decision the f32
+//               enclosure cannot certify is retaken from the f64 record in a RESOLVE step of the lane.  Same hits, same counters.
+template <int MODE, bool COUNT, bool HYB>
 __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& ps, const uint32_t* __restrict__ queue, const uint32_t n_first,
                                            const uint32_t* __restrict__ queue_b, const uint32_t n_b, const double* __restrict__ closest_tmax,
                                            Counters* ctr, unsigned int* work_head, unsigned int refill_min) {
@@ -58,24 +60,39 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
     unsigned long long n_nodes = 0, n_prims = 0, n_tri = 0;
     unsigned int overflow = 0;
 #ifdef CRAY_TRACE_DIAG
-    unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long dg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 
     // Traversal stack: the bottom kLdsStack entries of every lane live in LDS ([entry][thread], so a
-    // wave's access is conflict-free), deeper entries (rare) spill to scratch.
+    // wave's access is conflict-free), deeper entries (rare) spill to scratch.  An entry is 12 B: the child reference and its
+    // f64 key, or (HYB) the reference, the encoded f32 key estimate and parent | side << 31 for a later exact test.
     __shared__ uint32_t lds_ref[kLdsStack * kBlock];
-    __shared__ double lds_key[kLdsStack * kBlock];
+    __shared__ uint32_t lds_kw[kLdsStack * kBlock * 2];   // f64 key as two words [2 sp][thread] / [2 sp + 1][thread]; HYB: key, parent
     uint32_t sref[kStackDepth - kLdsStack];
-    double skey[kStackDepth - kLdsStack];
+    uint32_t skw0[kStackDepth - kLdsStack], skw1[kStackDepth - kLdsStack];
     const unsigned int tid = threadIdx.x;
-#define CRAY_PUSH(r_, k_)                                                                  \
+    // (r_: reference, w0_ / w1_: the two payload words)
+#define CRAY_PUSH_W(r_, w0_, w1_)                                                          \
     do {                                                                                   \
-        if (sp < kLdsStack) { lds_ref[sp * kBlock + tid] = (r_); lds_key[sp * kBlock + tid] = (k_); sp++; } \
-        else if (sp < kStackDepth) { sref[sp - kLdsStack] = (r_); skey[sp - kLdsStack] = (k_); sp++; }      \
+        if (sp < kLdsStack) { lds_ref[sp * kBlock + tid] = (r_); lds_kw[(2 * sp) * kBlock + tid] = (w0_); lds_kw[(2 * sp + 1) * kBlock + tid] = (w1_); sp++; } \
+        else if (sp < kStackDepth) { sref[sp - kLdsStack] = (r_); skw0[sp - kLdsStack] = (w0_); skw1[sp - kLdsStack] = (w1_); sp++; }      \
         else if (sp < kStackDepth + (int)ctr->deep_depth) {                                \
             const size_t at_ = (size_t)(sp - kStackDepth) * ((size_t)gridDim.x * kBlock) + (size_t)blockIdx.x * kBlock + tid; \
-            ctr->deep_ref[at_] = (r_); ctr->deep_key[at_] = (k_); sp++;                    \
+            ctr->deep_ref[at_] = (r_);                                                     \
+            ctr->deep_key[at_] = __hiloint2double((int)(w1_), (int)(w0_)); sp++;           \
         } else overflow = 1;                                                               \
+    } while (0)
+#define CRAY_PUSH(r_, k_) CRAY_PUSH_W(r_, (uint32_t)__double2loint(k_), (uint32_t)__double2hiint(k_))
+#define CRAY_PUSH_H(r_, kc_, par_) CRAY_PUSH_W(r_, __float_as_uint(kc_), (par_))
+#define CRAY_POP_W(r_, w0_, w1_)                                                           \
+    do {                                                                                   \
+        if (sp < kLdsStack) { r_ = lds_ref[sp * kBlock + tid]; w0_ = lds_kw[(2 * sp) * kBlock + tid]; w1_ = lds_kw[(2 * sp + 1) * kBlock + tid]; } \
+        else if (sp < kStackDepth) { r_ = sref[sp - kLdsStack]; w0_ = skw0[sp - kLdsStack]; w1_ = skw1[sp - kLdsStack]; }               \
+        else {                                                                             \
+            const size_t at_ = (size_t)(sp - kStackDepth) * ((size_t)gridDim.x * kBlock) + (size_t)blockIdx.x * kBlock + tid; \
+            const double dk_ = ctr->deep_key[at_];                                         \
+            r_ = ctr->deep_ref[at_]; w0_ = (uint32_t)__double2loint(dk_); w1_ = (uint32_t)__double2hiint(dk_);  \
+        }                                                                                  \
     } while (0)
     int sp = 0;
     bool active = false, exhausted = false;
@@ -90,8 +107,16 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
     ray_t ray = mkray(mk(0, 0, 0), mk(0, 0, 1));
     vec3 rd = mk(0, 0, 1);   // 1 / ray.d per axis (exact-division helper)
     bool fast_div = false;   // operands of this ray are inside div_fast's proven range
+    uint32_t dneg = 0;       // bit k: ray.d[k] < 0 (the child order at a node split on axis k)
     double hit_t = 0.0, hit_u = 0.0, hit_v = 0.0;
     int32_t hit_prim = -1;
+    // HYB: the f32 view of the ray, [t_lo, t_hi] around ray.tmax, and the RESOLVE state: `cur` was reached on an uncertified
+    // decision, `res` = parent | side << 31 names the f64 bounds that decide it
+    HybRay hr;
+    hr.o[0] = hr.o[1] = hr.o[2] = 0.f; hr.r[0] = hr.r[1] = hr.r[2] = 1.f; hr.a = 0.f;
+    float t_lo = 0.f, t_hi = 0.f;
+    uint32_t res = 0;
+    bool resolve = false;
 
     for (;;) {
         // ---- idle lanes fetch the next rays of the queue.  A wave reserves a chunk of consecutive queue
@@ -153,8 +178,14 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
                 hit_t = 0.0; hit_u = 0.0; hit_v = 0.0; hit_prim = -1;
                 sp = 0;
                 rd = mk(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
+                dneg = (ray.d.x < 0.0 ? 1u : 0u) | (ray.d.y < 0.0 ? 2u : 0u) | (ray.d.z < 0.0 ? 4u : 0u);
                 fast_div = sc.bounds_in_div_range && div_fast_ok(ray.d.x) && div_fast_ok(ray.d.y) && div_fast_ok(ray.d.z) &&
                            div_range_ok(ray.o.x) && div_range_ok(ray.o.y) && div_range_ok(ray.o.z);
+                if (HYB) {
+                    hr = hyb_ray(ray.o, ray.d, rd, fast_div);
+                    hyb_tmax(ray.tmax, t_lo, t_hi);
+                    resolve = false;
+                }
                 if (COUNT) n_nodes += 1;
                 const double k_root = fast_div ? child_key_fast(sc.root_lo, sc.root_hi, ray.o, ray.d, rd)
                                                : child_key(sc.root_lo, sc.root_hi, ray.o, ray.d);
@@ -175,23 +206,81 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
 #ifdef CRAY_TRACE_DIAG
         {
             const unsigned int na = (unsigned int)__popcll(__ballot(active));
-            const unsigned int nl = (unsigned int)__popcll(__ballot(active && ref_is_leaf(cur)));
-            dg[0] += 1; dg[1] += na; dg[6] += na - nl; dg[7] += nl;
+            const unsigned int nr = HYB ? (unsigned int)__popcll(__ballot(active && resolve)) : 0u;
+            const unsigned int nl = (unsigned int)__popcll(__ballot(active && !(HYB && resolve) && ref_is_leaf(cur)));
+            dg[0] += 1; dg[1] += na; dg[6] += na - nl - nr; dg[7] += nl; dg[8] += nr; dg[9] += nr ? 1 : 0;
+            dg[10] += nl ? 1 : 0;
+            {
+                // leaves whose FIRST slot is not a triangle, leaves with more than one slot (diagnostics read the slot kind themselves)
+                bool other = false, multi = false;
+                if (active && !(HYB && resolve) && ref_is_leaf(cur)) {
+                    other = sc.slots[ref_leaf_first(cur)].kind != CRAY_SHAPE_TRIANGLE;
+                    multi = ref_leaf_count(cur) > 1;
+                }
+                dg[11] += __any(other) ? 1 : 0; dg[12] += __any(multi) ? 1 : 0;
+                dg[13] += (unsigned int)__popcll(__ballot(other));
+            }
             if (exhausted) { dg[2] += 1; dg[3] += na; }
         }
 #endif
         // ---- one record fetch per iteration: the interior node `cur` (7 x 16 B) or the first slot of
         // the leaf `cur` (5 x 16 B) through the SAME seven load instructions, hence one memory wait per
         // iteration for the whole wave instead of one for the node and a dependent one for the leaf.
-        const bool at_leaf = ref_is_leaf(cur);
+        // HYB: the interior node is 4 x 16 B of f32, a RESOLVE step reads the 3 x 16 B of one child's f64 bounds: five loads.
+        const bool at_leaf = !(HYB && resolve) && ref_is_leaf(cur);
         double2 r0, r1, r2, r3, r4, r5, r6;
         r0 = r1 = r2 = r3 = r4 = r5 = r6 = make_double2(0.0, 0.0);
-        if (active) {
+        if (HYB) {
+            if (active) {
+                const double2* rec = resolve ? reinterpret_cast<const double2*>(reinterpret_cast<const char*>(sc.inner + (res & 0x7fffffffu)) + (res >> 31) * 48u)
+                                   : at_leaf ? reinterpret_cast<const double2*>(sc.slots + ref_leaf_first(cur))
+                                             : reinterpret_cast<const double2*>(sc.inner32 + cur);
+                r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
+                if (!resolve) r3 = rec[3];
+                if (at_leaf) r4 = rec[4];
+            }
+        } else if (active) {
             const double2* rec = at_leaf ? reinterpret_cast<const double2*>(sc.slots + ref_leaf_first(cur))
                                          : reinterpret_cast<const double2*>(sc.inner + cur);
             r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3]; r4 = rec[4]; r5 = rec[5]; r6 = rec[6];
         }
-        if (active && !at_leaf) {
+        if (HYB && active && resolve) {
+            // the decision that brought the lane to `cur`, retaken exactly (bounds.rs:46-88 in f64)
+            const double lo[3] = {r0.x, r0.y, r1.x}, hi[3] = {r1.y, r2.x, r2.y};
+            const double key = fast_div ? child_key_fast(lo, hi, ray.o, ray.d, rd) : child_key(lo, hi, ray.o, ray.d);
+            resolve = false;
+            if (!(key < ray.tmax)) need_pop = true;   // otherwise the lane is at `cur` for good: its record is fetched next iteration
+        } else if (HYB && active && !at_leaf) {
+#define CRAY_F2(d_, lo_, hi_) const float lo_ = __uint_as_float((uint32_t)__double2loint(d_)), hi_ = __uint_as_float((uint32_t)__double2hiint(d_))
+            CRAY_F2(r0.x, f0, f1); CRAY_F2(r0.y, f2, f3); CRAY_F2(r1.x, f4, f5); CRAY_F2(r1.y, f6, f7);
+            CRAY_F2(r2.x, f8, f9); CRAY_F2(r2.y, f10, f11);
+#undef CRAY_F2
+            const float lo0[3] = {f0, f1, f2}, hi0[3] = {f3, f4, f5}, lo1[3] = {f6, f7, f8}, hi1[3] = {f9, f10, f11};
+            const uint32_t ref0 = (uint32_t)__double2loint(r3.x), ref1 = (uint32_t)__double2hiint(r3.x);
+            const uint32_t axis = (uint32_t)__double2loint(r3.y);
+            const float kc0 = hyb_key(lo0, hi0, hr), kc1 = hyb_key(lo1, hi1, hr);
+            const bool right_first = ((dneg >> axis) & 1u) != 0;   // bvh.rs:92-98: dir[axis] < 0
+            const uint32_t near = right_first ? ref1 : ref0, far = right_first ? ref0 : ref1;
+            const float kcn = right_first ? kc1 : kc0, kcf = right_first ? kc0 : kc1;
+            const uint32_t par_n = cur | (right_first ? 0x80000000u : 0u), par_f = cur | (right_first ? 0u : 0x80000000u);
+            const int sn = hyb_status(kcn, hr.a, t_lo, t_hi), sf = hyb_status(kcf, hr.a, t_lo, t_hi);
+            if (COUNT && !ANY) n_nodes += 2;  // both children are popped and tested by the reference
+            if (COUNT && ANY) {
+                // count pops in the reference's order: near now, far when (if) it is popped
+                n_nodes += 1;
+                CRAY_PUSH_H(far, kcf, par_f);
+                if (sn != kHybCull) { cur = near; res = par_n; resolve = sn == kHybResolve; } else need_pop = true;
+            } else if (sn != kHybCull) {
+                // an uncertified far child is deferred like a certified one: its key does not depend on ray.tmax, the test
+                // at its pop (certified then, or exact) is the reference's test of that pop
+                if (sf != kHybCull) CRAY_PUSH_H(far, kcf, par_f);
+                cur = near; res = par_n; resolve = sn == kHybResolve;
+            } else if (sf != kHybCull) {
+                cur = far; res = par_f; resolve = sf == kHybResolve;
+            } else {
+                need_pop = true;
+            }
+        } else if (!HYB && active && !at_leaf) {
             const double lo0[3] = {r0.x, r0.y, r1.x}, hi0[3] = {r1.y, r2.x, r2.y};
             const double lo1[3] = {r3.x, r3.y, r4.x}, hi1[3] = {r4.y, r5.x, r5.y};
             const unsigned long long refs = (unsigned long long)__double_as_longlong(r6.x);
@@ -201,7 +290,7 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
             if (fast_div) { k0 = child_key_fast(lo0, hi0, ray.o, ray.d, rd); k1 = child_key_fast(lo1, hi1, ray.o, ray.d, rd); }
             else { k0 = child_key(lo0, hi0, ray.o, ray.d); k1 = child_key(lo1, hi1, ray.o, ray.d); }
             // bvh.rs:92-98: dir[axis] < 0 -> push left, push right => right is visited first
-            const bool right_first = comp(ray.d, (int)axis) < 0.0;
+            const bool right_first = ((dneg >> axis) & 1u) != 0;
             const uint32_t near = right_first ? ref1 : ref0, far = right_first ? ref0 : ref1;
             const double kn = right_first ? k1 : k0, kf = right_first ? k0 : k1;
             const bool an = kn < ray.tmax, af = kf < ray.tmax;
@@ -220,34 +309,39 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
                 need_pop = true;
             }
         } else if (active) {
-            const uint32_t first = ref_leaf_first(cur), count = ref_leaf_count(cur);
-            for (uint32_t k = 0; k < count; k++) {
-                if (k > 0) {  // further primitives of the leaf (13 % of the leaves hold 2, none more than 4)
-                    const double2* rec = reinterpret_cast<const double2*>(sc.slots + first + k);
-                    r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3]; r4 = rec[4];
-                }
-                const unsigned long long tag = (unsigned long long)__double_as_longlong(r4.y);
-                const uint32_t s_prim = (uint32_t)tag, s_kind = (uint32_t)(tag >> 32);
-                if (COUNT) n_prims += 1;
-                if (s_kind == CRAY_SHAPE_TRIANGLE) {
-                    if (COUNT) n_tri += 1;
-                    double t, u, v;
-                    if (tri_test(mk(r0.x, r0.y, r1.x), mk(r1.y, r2.x, r2.y), mk(r3.x, r3.y, r4.x), ray, t, u, v)) {
-                        if (CRAY_ANY_LANE) { occluded = true; break; }
+            // ONE slot per iteration: a leaf of several primitives (13 % of the dragon's hold 2, none more than 4) keeps its lane
+            // for as many iterations — `cur` steps to the leaf's remaining slots — so that no iteration waits for a second,
+            // dependent record fetch (a quarter to a half of all iterations did) and the later slots of one lane are tested
+            // together with the first slots of others.
+            const unsigned long long tag = (unsigned long long)__double_as_longlong(r4.y);
+            const uint32_t s_prim = (uint32_t)tag, s_kind = (uint32_t)(tag >> 32);
+            if (COUNT) n_prims += 1;
+            if (s_kind == CRAY_SHAPE_TRIANGLE) {
+                if (COUNT) n_tri += 1;
+                double t, u, v;
+                if (tri_test(mk(r0.x, r0.y, r1.x), mk(r1.y, r2.x, r2.y), mk(r3.x, r3.y, r4.x), ray, t, u, v)) {
+                    if (CRAY_ANY_LANE) occluded = true;
+                    else {
                         ray.tmax = t;  // Ray::update_max_distance
+                        if (HYB) hyb_tmax(t, t_lo, t_hi);
                         hit_t = t; hit_u = u; hit_v = v; hit_prim = (int32_t)s_prim;
                     }
-                } else {
-                    const cray_prim& pr = sc.prims[s_prim];
-                    bool hit = s_kind == CRAY_SHAPE_SPHERE ? sphere_hit(sc.spheres[pr.shape], ray, CRAY_ANY_LANE, nullptr)
-                                                         : disk_hit(sc.disks[pr.shape], ray, CRAY_ANY_LANE, nullptr);
-                    if (hit) {
-                        if (CRAY_ANY_LANE) { occluded = true; break; }
+                }
+            } else {
+                const cray_prim& pr = sc.prims[s_prim];
+                const bool hit = s_kind == CRAY_SHAPE_SPHERE ? sphere_hit(sc.spheres[pr.shape], ray, CRAY_ANY_LANE, nullptr)
+                                                             : disk_hit(sc.disks[pr.shape], ray, CRAY_ANY_LANE, nullptr);
+                if (hit) {
+                    if (CRAY_ANY_LANE) occluded = true;
+                    else {
                         hit_t = ray.tmax; hit_prim = (int32_t)s_prim;  // distance: ray.max_distance (primitive.rs:66)
+                        if (HYB) hyb_tmax(ray.tmax, t_lo, t_hi);
                     }
                 }
             }
-            if (CRAY_ANY_LANE && occluded) finished = true; else need_pop = true;
+            if (CRAY_ANY_LANE && occluded) finished = true;
+            else if (ref_leaf_count(cur) > 1) cur += 7u;   // first slot + 1 (<< 3), count - 1
+            else need_pop = true;
         }
         // ---- pop: a deferred child is re-tested against the current (shrunken) ray.tmax
         if (active && need_pop) {
@@ -255,15 +349,15 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
                 if (sp == 0) { finished = true; break; }
                 --sp;
                 if (COUNT && ANY) n_nodes += 1;
-                double key;
-                uint32_t ref;
-                if (sp < kLdsStack) { key = lds_key[sp * kBlock + tid]; ref = lds_ref[sp * kBlock + tid]; }
-                else if (sp < kStackDepth) { key = skey[sp - kLdsStack]; ref = sref[sp - kLdsStack]; }
-                else {
-                    const size_t at = (size_t)(sp - kStackDepth) * ((size_t)gridDim.x * kBlock) + (size_t)blockIdx.x * kBlock + tid;
-                    key = ctr->deep_key[at]; ref = ctr->deep_ref[at];
+                uint32_t ref, w0, w1;
+                CRAY_POP_W(ref, w0, w1);
+                if (HYB) {
+                    const int st = hyb_status(__uint_as_float(w0), hr.a, t_lo, t_hi);
+                    if (st != kHybCull) { cur = ref; res = w1; resolve = st == kHybResolve; break; }
+                } else {
+                    const double key = __hiloint2double((int)w1, (int)w0);
+                    if (key < ray.tmax) { cur = ref; break; }
                 }
-                if (key < ray.tmax) { cur = ref; break; }
             }
         }
         if (active && finished) {
@@ -287,25 +381,29 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
     if (overflow) atomicAdd(&ctr->stack_overflow, 1ull);
 #ifdef CRAY_TRACE_DIAG
     if (lane == 0)
-        for (int k = 0; k < 8; k++) atomicAdd(&ctr->diag[(ANY ? 8 : 0) + k], dg[k]);
+        for (int k = 0; k < 16; k++) atomicAdd(&ctr->diag[(ANY ? 16 : 0) + k], dg[k]);
 #endif
 #undef CRAY_PUSH
+#undef CRAY_PUSH_H
+#undef CRAY_PUSH_W
+#undef CRAY_POP_W
 #undef CRAY_ANY_LANE
 }
 
-template <bool ANY, bool COUNT>
+template <bool ANY, bool COUNT, bool HYB>
 __global__ void __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace(DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
                                                   const unsigned int* __restrict__ n_ptr, uint32_t n_fixed,
                                                   const double* __restrict__ closest_tmax, Counters* ctr, unsigned int* work_head, unsigned int refill_min) {
-    trace_body<ANY ? kTraceAny : kTraceClosest, COUNT>(sc, ps, queue, n_ptr ? *n_ptr : n_fixed, nullptr, 0u, closest_tmax, ctr, work_head, refill_min);
+    trace_body<ANY ? kTraceAny : kTraceClosest, COUNT, HYB>(sc, ps, queue, n_ptr ? *n_ptr : n_fixed, nullptr, 0u, closest_tmax, ctr, work_head, refill_min);
 }
 
 // shadow rays of one bounce (any_queue) + path segments of the next (closest_queue) in one persistent launch
+template <bool HYB>
 __global__ void __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace_mixed(DevScene sc, PathState ps, const uint32_t* __restrict__ any_queue,
                                                   const unsigned int* __restrict__ n_any_ptr, const uint32_t* __restrict__ closest_queue,
                                                   const unsigned int* __restrict__ n_closest_ptr, Counters* ctr, unsigned int* work_head,
                                                   unsigned int refill_min) {
-    trace_body<kTraceMixed, false>(sc, ps, any_queue, *n_any_ptr, closest_queue, *n_closest_ptr, nullptr, ctr, work_head, refill_min);
+    trace_body<kTraceMixed, false, HYB>(sc, ps, any_queue, *n_any_ptr, closest_queue, *n_closest_ptr, nullptr, ctr, work_head, refill_min);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -406,7 +504,11 @@ __device__ __forceinline__ void trace_body32(const DevScene& sc, const PathState
                 d[0] = (float)ray.d.x; d[1] = (float)ray.d.y; d[2] = (float)ray.d.z;
                 rd[0] = 1.0f / d[0]; rd[1] = 1.0f / d[1]; rd[2] = 1.0f / d[2];
                 // a shadow ray ends 1e-9 before its light (light.rs:125-128): in f32 that margin must be relative
+#ifdef CRAY_T32_F64LEAF
+                tmax = CRAY_ANY_LANE ? __double2float_ru(ray.tmax) : __builtin_huge_valf();
+#else
                 tmax = CRAY_ANY_LANE ? __double2float_rd(ray.tmax) * 0.99998f : __builtin_huge_valf();
+#endif
                 t_lo = 1e-4f * fmaxf(1.0f, fmaxf(fabsf(o[0]), fmaxf(fabsf(o[1]), fabsf(o[2]))));
                 hit_t = 0.0; hit_u = 0.0; hit_v = 0.0; hit_prim = -1;
                 sp = 0;
@@ -425,11 +527,21 @@ __device__ __forceinline__ void trace_body32(const DevScene& sc, const PathState
         const bool at_leaf = ref_is_leaf(cur);
         float4 r0, r1, r2, r3;
         r0 = r1 = r2 = r3 = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifdef CRAY_T32_F64LEAF
+        float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (active) {
+            const float4* rec = at_leaf ? reinterpret_cast<const float4*>(sc.slots + ref_leaf_first(cur))
+                                        : reinterpret_cast<const float4*>(sc.inner32 + cur);
+            r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3];
+            if (at_leaf) r4 = rec[4];
+        }
+#else
         if (active) {
             const float4* rec = at_leaf ? reinterpret_cast<const float4*>(sc.slots32 + ref_leaf_first(cur))
                                         : reinterpret_cast<const float4*>(sc.inner32 + cur);
             r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3];
         }
+#endif
         if (active && !at_leaf) {
             const float lo0[3] = {r0.x, r0.y, r0.z}, hi0[3] = {r0.w, r1.x, r1.y};
             const float lo1[3] = {r1.z, r1.w, r2.x}, hi1[3] = {r2.y, r2.z, r2.w};
@@ -454,11 +566,30 @@ __device__ __forceinline__ void trace_body32(const DevScene& sc, const PathState
         } else if (active) {
             const uint32_t first = ref_leaf_first(cur), count = ref_leaf_count(cur);
             for (uint32_t k = 0; k < count; k++) {
+#ifdef CRAY_T32_F64LEAF
+                if (k > 0) {
+                    const float4* rec = reinterpret_cast<const float4*>(sc.slots + first + k);
+                    r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3]; r4 = rec[4];
+                }
+                const uint32_t s_prim = __float_as_uint(r4.z), s_kind = __float_as_uint(r4.w);
+                if (s_kind == CRAY_SHAPE_TRIANGLE) {
+#define CRAY_D2(a_, b_) __hiloint2double((int)__float_as_uint(b_), (int)__float_as_uint(a_))
+                    double t, u, v;
+                    if (tri_test(mk(CRAY_D2(r0.x, r0.y), CRAY_D2(r0.z, r0.w), CRAY_D2(r1.x, r1.y)), mk(CRAY_D2(r1.z, r1.w), CRAY_D2(r2.x, r2.y), CRAY_D2(r2.z, r2.w)),
+                                 mk(CRAY_D2(r3.x, r3.y), CRAY_D2(r3.z, r3.w), CRAY_D2(r4.x, r4.y)), ray, t, u, v)) {
+                        if (CRAY_ANY_LANE) { occluded = true; break; }
+                        ray.tmax = t; tmax = __double2float_ru(t);
+                        hit_t = t; hit_u = u; hit_v = v; hit_prim = (int32_t)s_prim;
+                    }
+                    continue;
+                }
+#else
                 if (k > 0) {
                     const float4* rec = reinterpret_cast<const float4*>(sc.slots32 + first + k);
                     r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
                 }
                 const uint32_t s_prim = __float_as_uint(r2.y), s_kind = __float_as_uint(r2.z);
+#endif
                 if (s_kind == CRAY_SHAPE_TRIANGLE) {
                     if ((int32_t)s_prim == skip) continue;
                     // Moller-Trumbore as in shape.rs:216-262, in f32

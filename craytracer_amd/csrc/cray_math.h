@@ -232,6 +232,113 @@ CRAY_HD double child_key_fast(const double* __restrict__ lo, const double* __res
     return inside ? -inf64() : key;
 }
 
+
+// ---------------------------------------------------------------------------------
+// Certified f32 culling ("hybrid" records).
+//
+// The traversal decides  key < ray.tmax  for every child box, with key = child_key (exact f64).  Most of those decisions are
+// nowhere near a tie, so they can be taken from a 64-B record of f32 bounds — HALF the bytes of the f64 record — provided the
+// f32 arithmetic carries a rigorous enclosure of the f64 values and every decision it cannot certify is retaken exactly from
+// the f64 record.  The result of the traversal (hits, node and primitive counters) is then bit for bit the f64 result.
+//
+// Notation: u = 2^-24.  For a ray inside hyb_ray_ok's range and a scene whose bounds are within 2^40:
+//   b32 = the f64 bound b rounded outward to f32            |b32 - b| <= 2u|b|        (k_make_inner32)
+//   o32 = RN32(o_i),  r32 = RN32(RN64(1/d_i))               |o32 - o| <= u|o|,  |r32 d - 1| <= u(1 + 2^-28)
+//   qt  = RN32(RN32(b32 - o32) * r32)                       the f32 slab quotient
+//   q   = RN64(RN64(b - o) / d)                             the reference's quotient (= div_fast, exactly)
+// With Q = (b - o)/d:  qt - q = Q[(1+d1)(1+d2)(1+rho) - (1+e1)(1+e2)] + ((b32-b) - (o32-o))/d (1+d1)(1+d2)(1+rho), hence, using
+// |b| <= |b - o| + |o|,        |qt - q| <= 5.02u |qt| + 3.02u |o_i| / |d_i|.
+// f+-(x) = x +- (a + c|x|) with c = 8u, a = 4u(1 + 2^-10) max_i |o_i| |1/d_i| (>= 2^-100: absorbs f32 underflow) are increasing,
+// so min / max over the axes commute with them:
+//   tmin in [f-(tmin32), f+(tmin32)],  tmax in [f-(tmax32), f+(tmax32)],   tmin32 / tmax32 = the plain f32 slab results.
+// The spare 2.98u|x| and 0.98u|o|/|d| cover the roundings of evaluating f+- themselves in f32.
+//
+// hyb_key classifies a box from the two enclosures (tl,th), (xl,xh) and returns an ENCODED key estimate kc:
+//   +inf    certainly no intersection (tmin > tmax, or tmax < 0)                      key = +inf
+//   -1e-30  the origin is certainly inside (tmin <= 0 <= tmax)                          key = -inf
+//   x > 0   certainly tmin > EPS and tmin <= tmax:                                      key = tmin in [f-(x), f+(x)]
+//   x < 0   certainly tmax > EPS and tmin <= tmax, tmin near 0 or EPS:                  key in {-inf, tmin, tmax} <= f+(|x|)
+//   NaN     nothing certain (grazing boxes, out-of-range rays: a = NaN)
+// hyb_status turns kc into a decision against ray.tmax in [T_lo, T_hi]:  V(isit)  key < tmax certainly,  C(ull)  key >= tmax
+// certainly,  R(esolve)  neither — the kernel then fetches the f64 bounds of that child and compares child_key exactly.
+// tests/test_hybrid_key.py checks on random and adversarial boxes (origins on faces, flat boxes, tmax equal to the key) that a
+// V or C is never wrong, on the host build of these same functions.
+// ---------------------------------------------------------------------------------
+// outward rounding of a bound to f32 (the records k_make_inner32 writes)
+CRAY_HD float f32_down(double x) {
+#ifdef __HIP_DEVICE_COMPILE__
+    return __double2float_rd(x);
+#else
+    const float f = (float)x;
+    return (double)f > x ? nextafterf(f, -__builtin_huge_valf()) : f;
+#endif
+}
+CRAY_HD float f32_up(double x) {
+#ifdef __HIP_DEVICE_COMPILE__
+    return __double2float_ru(x);
+#else
+    const float f = (float)x;
+    return (double)f < x ? nextafterf(f, __builtin_huge_valf()) : f;
+#endif
+}
+struct HybRay {
+    float o[3], r[3];
+    float a;   // NaN: this ray is outside the certified range, every decision is resolved exactly
+};
+constexpr float kHybC = 0x1p-21f;     // 8u
+constexpr float kHybEpsUp = 1.1e-9f;  // > EPS (1e-9) as a f32 threshold
+enum { kHybResolve = 0, kHybVisit = 1, kHybCull = 2 };
+
+CRAY_HD bool hyb_scene_ok(const double* root_lo, const double* root_hi) {  // every node's bounds lie inside the root's
+    bool ok = true;
+    for (int k = 0; k < 3; k++) ok = ok && fabs(root_lo[k]) <= 0x1p40 && fabs(root_hi[k]) <= 0x1p40;   // false for NaN
+    return ok;
+}
+CRAY_HD HybRay hyb_ray(vec3 o, vec3 d, vec3 rd, bool fast_div) {
+    HybRay h;
+    h.o[0] = (float)o.x; h.o[1] = (float)o.y; h.o[2] = (float)o.z;
+    h.r[0] = (float)rd.x; h.r[1] = (float)rd.y; h.r[2] = (float)rd.z;
+    const double ax = fabs(d.x), ay = fabs(d.y), az = fabs(d.z);
+    const bool ok = fast_div && ax >= 0x1p-30 && ax <= 0x1p30 && ay >= 0x1p-30 && ay <= 0x1p30 && az >= 0x1p-30 && az <= 0x1p30 &&
+                    fabs(o.x) <= 0x1p40 && fabs(o.y) <= 0x1p40 && fabs(o.z) <= 0x1p40;
+    const double m = fmax(fmax(fabs(o.x) * fabs(rd.x), fabs(o.y) * fabs(rd.y)), fabs(o.z) * fabs(rd.z));
+    const float a = (float)(m * (0x1p-22 * (1.0 + 0x1p-10)));
+    h.a = ok ? fmaxf(a, 0x1p-100f) : __builtin_nanf("");
+    return h;
+}
+// [T_lo, T_hi] around ray.tmax; everything is resolved exactly for a tmax that f32 cannot bracket this way
+CRAY_HD void hyb_tmax(double t, float& t_lo, float& t_hi) {
+    const float x = (float)t;
+    const bool ok = t >= 1e-30;   // false for NaN
+    t_lo = ok ? x * (1.0f - 0x1p-22f) : -__builtin_huge_valf();
+    t_hi = ok ? x * (1.0f + 0x1p-22f) : __builtin_huge_valf();
+}
+CRAY_HD float hyb_key(const float* lo, const float* hi, const HybRay& h) {
+    float tmin = -__builtin_huge_valf(), tmax = __builtin_huge_valf();
+#ifdef __HIP_DEVICE_COMPILE__
+#pragma unroll
+#endif
+    for (int k = 0; k < 3; k++) {
+        const float t0 = (lo[k] - h.o[k]) * h.r[k], t1 = (hi[k] - h.o[k]) * h.r[k];
+        tmin = fmaxf(tmin, fminf(t0, t1));
+        tmax = fminf(tmax, fmaxf(t0, t1));
+    }
+    const float e0 = fmaf(kHybC, fabsf(tmin), h.a), e1 = fmaf(kHybC, fabsf(tmax), h.a);
+    const float tl = tmin - e0, th = tmin + e0, xl = tmax - e1, xh = tmax + e1;
+    float kc = __builtin_nanf("");
+    if (th <= xl && xl > kHybEpsUp) kc = tl > kHybEpsUp ? tmin : -tmax;
+    if (th <= 0.0f && xl >= 0.0f) kc = -1e-30f;
+    if (tl > xh || xh < 0.0f) kc = __builtin_huge_valf();
+    return kc;
+}
+CRAY_HD int hyb_status(float kc, float a, float t_lo, float t_hi) {
+    const float m = fabsf(kc), e = fmaf(kHybC, m, a);
+    if (kc == __builtin_huge_valf()) return kHybCull;
+    if (m + e < t_lo) return kHybVisit;
+    if (kc > 0.0f && m - e >= t_hi) return kHybCull;
+    return kHybResolve;
+}
+
 }  // namespace cray
 
 // -----------------------------------------------------------------------------------------

@@ -58,6 +58,13 @@ uint64_t cray_host_div_fast_mismatches(const double* a, const double* d, uint64_
 uint64_t cray_host_child_key_mismatches(const double* lo, const double* hi, const double* o, const double* d, uint64_t n,
                                         uint64_t* n_checked);
 
+/* Certified f32 culling (cray_math.h hyb_key / hyb_status) against the literal slab test on n boxes, rays and
+ * ray.tmax values: returns how many times the f32 side certified a decision (visit: key < tmax, cull: key >= tmax) that the
+ * exact f64 key contradicts — must be 0.  counts[4] = decisions left to the exact path, certified visits, certified culls,
+ * rays outside the certified range. */
+uint64_t cray_host_hyb_key_violations(const double* lo, const double* hi, const double* o, const double* d, const double* tmax,
+                                      uint64_t n, uint64_t* counts);
+
 #ifdef __cplusplus
 }
 #endif
