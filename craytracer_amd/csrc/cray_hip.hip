@@ -71,7 +71,7 @@ struct cray_ctx {
     double* deep_key = nullptr;
     unsigned int deep_depth = 0;
     size_t deep_threads = 0;
-    int hybrid = 1;     // certified f32 culling in the exact traversal (CRAY_HYBRID=0: f64 records only)
+    int hybrid = 0;     // certified f32 culling in the exact traversal: opt-in (CRAY_HYBRID=1), same results, not faster as measured
     int mix_trace = 1;  // shadow rays of bounce b and segments of bounce b+1 in one launch (CRAY_MIX_TRACE=0 disables)
     Counters* counters = nullptr;
     uint32_t* pix_list = nullptr;
