@@ -64,6 +64,15 @@ struct alignas(16) LeafSlot32 {
 };
 static_assert(sizeof(LeafSlot32) == 48, "LeafSlot32 is three 16-B loads");
 
+// ---- certified f32 culling of the exact traversal (cray_math.h hyb_node): the two children's bounds, rounded outward to f32
+// and INTERLEAVED by child — (lo[axis][child], hi[axis][child]) — so that a 64-bit register pair holds one coordinate of both
+// boxes and the slab arithmetic of the pair is packed f32 math.
+struct alignas(64) InnerNodeH {
+    float lo[3][2], hi[3][2];
+    uint32_t ref0, ref1, axis, pad_;
+};
+static_assert(sizeof(InnerNodeH) == 64, "InnerNodeH is four 16-B loads");
+
 struct TriShade {
     double n0[3], n01[3], n02[3];
     double uv0[2], uv01[2], uv02[2];
@@ -96,6 +105,7 @@ struct DevScene {
     const InnerNode* inner;
     const LeafSlot* slots;
     const InnerNode32* inner32;   // fast mode only (built on first use)
+    const InnerNodeH* innerh;     // certified f32 culling only (built on first use)
     const LeafSlot32* slots32;
     // primitives
     const cray_prim* prims;

@@ -853,27 +853,34 @@ std::vector<uint32_t> rank_pixels(uint32_t W, uint32_t H, const cray_render_para
     return pix;
 }
 
-// The 64-B f32 interior records (bounds rounded outward), derived on the device from the f64 layout: read by the certified
-// f32 culling of the exact traversal (cray_math.h hyb_key) and by the fast mode.
+// The 64-B f32 interior records of the fast mode (bounds rounded outward), derived on the device from the f64 layout.
 int ensure_inner32(cray_ctx* c, cray_scene* s) {
     if (s->dev.inner32) return CRAY_OK;
     InnerNode32* i32 = nullptr;
     const uint32_t n_inner = s->dev.n_inner ? s->dev.n_inner : 1u;
-    HIP_TRY(hipMalloc((void**)&i32, ((size_t)n_inner + 1) * sizeof(InnerNode32)));   // + one: the 5-load fetch of a hybrid lane never leaves the array
+    HIP_TRY(hipMalloc((void**)&i32, (size_t)n_inner * sizeof(InnerNode32)));
     s->extra_allocs.push_back(i32);
-    HIP_TRY(hipMemsetAsync(i32, 0, ((size_t)n_inner + 1) * sizeof(InnerNode32), c->stream));
     hipLaunchKernelGGL(k_make_inner32, dim3((n_inner + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, s->dev.inner, n_inner, i32);
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipGetLastError());
-    s->bytes += ((size_t)n_inner + 1) * sizeof(InnerNode32);
+    s->bytes += (size_t)n_inner * sizeof(InnerNode32);
     s->dev.inner32 = i32;
     return CRAY_OK;
 }
 // Exact traversal with certified f32 culling: decided per scene (range of the bounds), records derived on first use.
 int ensure_hybrid(cray_ctx* c, cray_scene* s) {
     s->hybrid_ok = s->dev.bounds_in_div_range && hyb_scene_ok(s->dev.root_lo, s->dev.root_hi);
-    if (!c->hybrid || !s->hybrid_ok) return CRAY_OK;
-    return ensure_inner32(c, s);
+    if (!c->hybrid || !s->hybrid_ok || s->dev.innerh) return CRAY_OK;
+    InnerNodeH* ih = nullptr;
+    const uint32_t n_inner = s->dev.n_inner ? s->dev.n_inner : 1u;
+    HIP_TRY(hipMalloc((void**)&ih, (size_t)n_inner * sizeof(InnerNodeH)));
+    s->extra_allocs.push_back(ih);
+    hipLaunchKernelGGL(k_make_innerh, dim3((n_inner + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, s->dev.inner, n_inner, ih);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    s->bytes += (size_t)n_inner * sizeof(InnerNodeH);
+    s->dev.innerh = ih;
+    return CRAY_OK;
 }
 // The f32 triangle records of the fast mode, derived the first time a fast frame is asked for.
 int ensure_fast_layout(cray_ctx* c, cray_scene* s) {
@@ -931,7 +938,7 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
     // kind keeps its own launch so that the counters stay per kind.
     const bool mixed = !count && c->mix_trace;
     const bool fast = prm.precision == CRAY_PRECISION_F32_TRAVERSAL;   // check_render_args refuses it together with counting
-    const bool hyb = s->dev.inner32 != nullptr && c->hybrid && s->hybrid_ok;   // certified f32 culling (cray_math.h hyb_key): same results
+    const bool hyb = s->dev.innerh != nullptr && c->hybrid && s->hybrid_ok;   // certified f32 culling (cray_math.h hyb_key): same results
 #define CRAY_LAUNCH_TRACE(ANY_, COUNT_, ...)                                                                                   \
     do {                                                                                                                        \
         if (hyb) hipLaunchKernelGGL((k_trace<ANY_, COUNT_, true>), dim3(g_trace), dim3(kBlock), 0, st, __VA_ARGS__);              \
@@ -1282,7 +1289,7 @@ extern "C" int cray_trace(cray_ctx* c, cray_scene* s, const cray_ray* rays, size
     const int g = grid_for(c, n, 8);
     Counters* ctr = c->counters;
     if ((e = ensure_hybrid(c, s))) return e;
-    const bool hyb = s->dev.inner32 != nullptr && c->hybrid && s->hybrid_ok;
+    const bool hyb = s->dev.innerh != nullptr && c->hybrid && s->hybrid_ok;
     if (mixed) {
         // k_trace_mixed as the frame loop launches it: positions [0, n) of the virtual queue are the shadow rays of paths
         // 0..n-1 (an identity queue), positions [n, 2n) the path segments of the same paths (tmax = +inf, like Ray::new)
@@ -1766,7 +1773,7 @@ extern "C" int cray_scene_broadcast(cray_ctx* c, cray_scene* mine, int root, cra
         s->ctx = c; s->dev = h.dev; s->n_prims = h.n_prims;
         s->features = h.features; s->shade_variant = h.shade_variant;
         s->n_slots = h.n_slots;
-        s->dev.inner32 = nullptr; s->dev.slots32 = nullptr;   // the fast-mode records are derived per rank on first use
+        s->dev.inner32 = nullptr; s->dev.slots32 = nullptr; s->dev.innerh = nullptr;   // the fast-mode records are derived per rank on first use
         const void** fields[kSceneArrays];
         scene_arrays(s->dev, fields);
         for (int i = 0; i < kSceneArrays; i++) {

@@ -606,28 +606,46 @@ extern "C" uint64_t cray_host_hyb_key_violations(const double* lo, const double*
                                                  uint64_t n, uint64_t* counts /* [4]: resolve, visit, cull, out-of-range rays */) {
     using namespace cray;
     uint64_t bad = 0, cnt[4] = {0, 0, 0, 0};
-    for (uint64_t i = 0; i < n; i++) {
-        const double *l = lo + 3 * i, *h = hi + 3 * i, *oo = o + 3 * i, *dd = d + 3 * i;
-        bool box_ok = hyb_scene_ok(l, h), fast = true;
-        for (int k = 0; k < 3; k++) {
-            box_ok = box_ok && l[k] <= h[k];
-            fast = fast && div_fast_ok(dd[k]) && div_range_ok(oo[k]) && div_range_ok(l[k]) && div_range_ok(h[k]);
+    // boxes i and i + 1 are the two children of one node, tested by the ray and tmax of sample i through hyb_node (what the
+    // kernel runs at a node); box i again alone through hyb_key + hyb_status (what it runs at a pop)
+    for (uint64_t i = 0; i + 1 < n; i++) {
+        const double *oo = o + 3 * i, *dd = d + 3 * i;
+        bool box_ok = true, fast = true;
+        for (int c = 0; c < 2; c++) {
+            const double *l = lo + 3 * (i + c), *h = hi + 3 * (i + c);
+            box_ok = box_ok && hyb_scene_ok(l, h);
+            for (int k = 0; k < 3; k++) { box_ok = box_ok && l[k] <= h[k]; fast = fast && div_range_ok(l[k]) && div_range_ok(h[k]); }
         }
+        for (int k = 0; k < 3; k++) fast = fast && div_fast_ok(dd[k]) && div_range_ok(oo[k]);
         if (!box_ok) continue;   // such a scene never runs the hybrid kernel
         const vec3 ov = mk(oo[0], oo[1], oo[2]), dv = mk(dd[0], dd[1], dd[2]);
         const vec3 rd = mk(1.0 / dd[0], 1.0 / dd[1], 1.0 / dd[2]);
-        const double key = child_key(l, h, ov, dv);   // the literal restatement of the reference
         const HybRay hr = hyb_ray(ov, dv, rd, fast);
         if (hr.a != hr.a) cnt[3]++;
-        float l32[3], h32[3];
-        for (int k = 0; k < 3; k++) { l32[k] = f32_down(l[k]); h32[k] = f32_up(h[k]); }
-        const float kc = hyb_key(l32, h32, hr);
         float t_lo, t_hi;
         hyb_tmax(tmax[i], t_lo, t_hi);
-        const int st = hyb_status(kc, hr.a, t_lo, t_hi);
-        cnt[st]++;
-        const bool accept = key < tmax[i];
-        if ((st == kHybVisit && !accept) || (st == kHybCull && accept)) bad++;
+        hyb_f2 l32[3], h32[3];
+        for (int k = 0; k < 3; k++)
+            for (int c = 0; c < 2; c++) { l32[k][c] = f32_down(lo[3 * (i + c) + k]); h32[k][c] = f32_up(hi[3 * (i + c) + k]); }
+        const HybNode hn = hyb_node(l32[0], l32[1], l32[2], h32[0], h32[1], h32[2], hr.ox, hr.oy, hr.oz, hr.rx, hr.ry, hr.rz, hr.a, t_lo, t_hi);
+        for (int c = 0; c < 2; c++) {
+            const double key = child_key(lo + 3 * (i + c), hi + 3 * (i + c), ov, dv);   // the literal restatement of the reference
+            const bool accept = key < tmax[i];
+            const int st = hn.s[c];
+            if (c == 0) cnt[st]++;
+            if ((st == kHybVisit && !accept) || (st == kHybCull && accept)) bad++;
+            // the deferred form: the encoded key against another (smaller) tmax, as at a pop
+            const double tm2 = c == 0 ? tmax[i] : tmax[i] * 0.5;
+            float a_lo, a_hi;
+            hyb_tmax(tm2, a_lo, a_hi);
+            const int st2 = hyb_status(hn.kc[c], hr.a, a_lo, a_hi);
+            const bool accept2 = key < tm2;
+            if ((st2 == kHybVisit && !accept2) || (st2 == kHybCull && accept2)) bad++;
+        }
+        // the single-box classifier must encode the same key
+        float l1[3] = {l32[0][0], l32[1][0], l32[2][0]}, h1[3] = {h32[0][0], h32[1][0], h32[2][0]};
+        const float kc1 = hyb_key(l1, h1, hr);
+        if (memcmp(&kc1, &hn.kc[0], 4) != 0 && !(kc1 != kc1 && hn.kc[0] != hn.kc[0])) bad++;
     }
     if (counts) for (int k = 0; k < 4; k++) counts[k] = cnt[k];
     return bad;

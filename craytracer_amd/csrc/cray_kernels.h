@@ -112,8 +112,8 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
     int32_t hit_prim = -1;
     // HYB: the f32 view of the ray, [t_lo, t_hi] around ray.tmax, and the RESOLVE state: `cur` was reached on an uncertified
     // decision, `res` = parent | side << 31 names the f64 bounds that decide it
-    HybRay hr;
-    hr.o[0] = hr.o[1] = hr.o[2] = 0.f; hr.r[0] = hr.r[1] = hr.r[2] = 1.f; hr.a = 0.f;
+    float h_ox = 0.f, h_oy = 0.f, h_oz = 0.f, h_rx = 1.f, h_ry = 1.f, h_rz = 1.f, h_a = 0.f;   // HybRay, kept as scalars (an aggregate in the
+                                                                                              // lane state ends up partly in LDS)
     float t_lo = 0.f, t_hi = 0.f;
     uint32_t res = 0;
     bool resolve = false;
@@ -182,7 +182,8 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
                 fast_div = sc.bounds_in_div_range && div_fast_ok(ray.d.x) && div_fast_ok(ray.d.y) && div_fast_ok(ray.d.z) &&
                            div_range_ok(ray.o.x) && div_range_ok(ray.o.y) && div_range_ok(ray.o.z);
                 if (HYB) {
-                    hr = hyb_ray(ray.o, ray.d, rd, fast_div);
+                    const HybRay hr_ = hyb_ray(ray.o, ray.d, rd, fast_div);
+                    h_ox = hr_.ox; h_oy = hr_.oy; h_oz = hr_.oz; h_rx = hr_.rx; h_ry = hr_.ry; h_rz = hr_.rz; h_a = hr_.a;
                     hyb_tmax(ray.tmax, t_lo, t_hi);
                     resolve = false;
                 }
@@ -239,7 +240,7 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
             if (active) {
                 const double2* rec = resolve ? reinterpret_cast<const double2*>(reinterpret_cast<const char*>(sc.inner + (res & 0x7fffffffu)) + (res >> 31) * 48u)
                                    : at_leaf ? reinterpret_cast<const double2*>(sc.slots + ref_leaf_first(cur))
-                                             : reinterpret_cast<const double2*>(sc.inner32 + cur);
+                                             : reinterpret_cast<const double2*>(sc.innerh + cur);
                 r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
                 if (!resolve) r3 = rec[3];
                 if (at_leaf) r4 = rec[4];
@@ -256,19 +257,17 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
             resolve = false;
             if (!(key < ray.tmax)) need_pop = true;   // otherwise the lane is at `cur` for good: its record is fetched next iteration
         } else if (HYB && active && !at_leaf) {
-#define CRAY_F2(d_, lo_, hi_) const float lo_ = __uint_as_float((uint32_t)__double2loint(d_)), hi_ = __uint_as_float((uint32_t)__double2hiint(d_))
-            CRAY_F2(r0.x, f0, f1); CRAY_F2(r0.y, f2, f3); CRAY_F2(r1.x, f4, f5); CRAY_F2(r1.y, f6, f7);
-            CRAY_F2(r2.x, f8, f9); CRAY_F2(r2.y, f10, f11);
+            // a double of the record = one coordinate of both children (InnerNodeH)
+#define CRAY_F2(d_) __builtin_bit_cast(hyb_f2, d_)
+            const HybNode hn = hyb_node(CRAY_F2(r0.x), CRAY_F2(r0.y), CRAY_F2(r1.x), CRAY_F2(r1.y), CRAY_F2(r2.x), CRAY_F2(r2.y), h_ox, h_oy, h_oz, h_rx, h_ry, h_rz, h_a, t_lo, t_hi);
 #undef CRAY_F2
-            const float lo0[3] = {f0, f1, f2}, hi0[3] = {f3, f4, f5}, lo1[3] = {f6, f7, f8}, hi1[3] = {f9, f10, f11};
             const uint32_t ref0 = (uint32_t)__double2loint(r3.x), ref1 = (uint32_t)__double2hiint(r3.x);
             const uint32_t axis = (uint32_t)__double2loint(r3.y);
-            const float kc0 = hyb_key(lo0, hi0, hr), kc1 = hyb_key(lo1, hi1, hr);
             const bool right_first = ((dneg >> axis) & 1u) != 0;   // bvh.rs:92-98: dir[axis] < 0
             const uint32_t near = right_first ? ref1 : ref0, far = right_first ? ref0 : ref1;
-            const float kcn = right_first ? kc1 : kc0, kcf = right_first ? kc0 : kc1;
+            const float kcf = right_first ? hn.kc[0] : hn.kc[1];
             const uint32_t par_n = cur | (right_first ? 0x80000000u : 0u), par_f = cur | (right_first ? 0u : 0x80000000u);
-            const int sn = hyb_status(kcn, hr.a, t_lo, t_hi), sf = hyb_status(kcf, hr.a, t_lo, t_hi);
+            const int sn = right_first ? hn.s[1] : hn.s[0], sf = right_first ? hn.s[0] : hn.s[1];
             if (COUNT && !ANY) n_nodes += 2;  // both children are popped and tested by the reference
             if (COUNT && ANY) {
                 // count pops in the reference's order: near now, far when (if) it is popped
@@ -358,7 +357,7 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
                 uint32_t ref, w0, w1;
                 CRAY_POP_W(ref, w0, w1);
                 if (HYB) {
-                    const int st = hyb_status(__uint_as_float(w0), hr.a, t_lo, t_hi);
+                    const int st = hyb_status(__uint_as_float(w0), h_a, t_lo, t_hi);
                     if (st != kHybCull) { cur = ref; res = w1; resolve = st == kHybResolve; break; }
                 } else {
                     const double key = __hiloint2double((int)w1, (int)w0);
@@ -510,11 +509,7 @@ __device__ __forceinline__ void trace_body32(const DevScene& sc, const PathState
                 d[0] = (float)ray.d.x; d[1] = (float)ray.d.y; d[2] = (float)ray.d.z;
                 rd[0] = 1.0f / d[0]; rd[1] = 1.0f / d[1]; rd[2] = 1.0f / d[2];
                 // a shadow ray ends 1e-9 before its light (light.rs:125-128): in f32 that margin must be relative
-#ifdef CRAY_T32_F64LEAF
-                tmax = CRAY_ANY_LANE ? __double2float_ru(ray.tmax) : __builtin_huge_valf();
-#else
                 tmax = CRAY_ANY_LANE ? __double2float_rd(ray.tmax) * 0.99998f : __builtin_huge_valf();
-#endif
                 t_lo = 1e-4f * fmaxf(1.0f, fmaxf(fabsf(o[0]), fmaxf(fabsf(o[1]), fabsf(o[2]))));
                 hit_t = 0.0; hit_u = 0.0; hit_v = 0.0; hit_prim = -1;
                 sp = 0;
@@ -533,21 +528,11 @@ __device__ __forceinline__ void trace_body32(const DevScene& sc, const PathState
         const bool at_leaf = ref_is_leaf(cur);
         float4 r0, r1, r2, r3;
         r0 = r1 = r2 = r3 = make_float4(0.f, 0.f, 0.f, 0.f);
-#ifdef CRAY_T32_F64LEAF
-        float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (active) {
-            const float4* rec = at_leaf ? reinterpret_cast<const float4*>(sc.slots + ref_leaf_first(cur))
-                                        : reinterpret_cast<const float4*>(sc.inner32 + cur);
-            r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3];
-            if (at_leaf) r4 = rec[4];
-        }
-#else
         if (active) {
             const float4* rec = at_leaf ? reinterpret_cast<const float4*>(sc.slots32 + ref_leaf_first(cur))
                                         : reinterpret_cast<const float4*>(sc.inner32 + cur);
             r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3];
         }
-#endif
         if (active && !at_leaf) {
             const float lo0[3] = {r0.x, r0.y, r0.z}, hi0[3] = {r0.w, r1.x, r1.y};
             const float lo1[3] = {r1.z, r1.w, r2.x}, hi1[3] = {r2.y, r2.z, r2.w};
@@ -572,30 +557,11 @@ __device__ __forceinline__ void trace_body32(const DevScene& sc, const PathState
         } else if (active) {
             const uint32_t first = ref_leaf_first(cur), count = ref_leaf_count(cur);
             for (uint32_t k = 0; k < count; k++) {
-#ifdef CRAY_T32_F64LEAF
-                if (k > 0) {
-                    const float4* rec = reinterpret_cast<const float4*>(sc.slots + first + k);
-                    r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3]; r4 = rec[4];
-                }
-                const uint32_t s_prim = __float_as_uint(r4.z), s_kind = __float_as_uint(r4.w);
-                if (s_kind == CRAY_SHAPE_TRIANGLE) {
-#define CRAY_D2(a_, b_) __hiloint2double((int)__float_as_uint(b_), (int)__float_as_uint(a_))
-                    double t, u, v;
-                    if (tri_test(mk(CRAY_D2(r0.x, r0.y), CRAY_D2(r0.z, r0.w), CRAY_D2(r1.x, r1.y)), mk(CRAY_D2(r1.z, r1.w), CRAY_D2(r2.x, r2.y), CRAY_D2(r2.z, r2.w)),
-                                 mk(CRAY_D2(r3.x, r3.y), CRAY_D2(r3.z, r3.w), CRAY_D2(r4.x, r4.y)), ray, t, u, v)) {
-                        if (CRAY_ANY_LANE) { occluded = true; break; }
-                        ray.tmax = t; tmax = __double2float_ru(t);
-                        hit_t = t; hit_u = u; hit_v = v; hit_prim = (int32_t)s_prim;
-                    }
-                    continue;
-                }
-#else
                 if (k > 0) {
                     const float4* rec = reinterpret_cast<const float4*>(sc.slots32 + first + k);
                     r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
                 }
                 const uint32_t s_prim = __float_as_uint(r2.y), s_kind = __float_as_uint(r2.z);
-#endif
                 if (s_kind == CRAY_SHAPE_TRIANGLE) {
                     if ((int32_t)s_prim == skip) continue;
                     // Moller-Trumbore as in shape.rs:216-262, in f32
@@ -674,6 +640,18 @@ __global__ void __launch_bounds__(kBlock) k_make_inner32(const InnerNode* __rest
     for (int k = 0; k < 3; k++) {
         o.lo0[k] = __double2float_rd(a.lo0[k]); o.hi0[k] = __double2float_ru(a.hi0[k]);
         o.lo1[k] = __double2float_rd(a.lo1[k]); o.hi1[k] = __double2float_ru(a.hi1[k]);
+    }
+    o.ref0 = a.ref0; o.ref1 = a.ref1; o.axis = a.axis; o.pad_ = 0;
+    out[i] = o;
+}
+__global__ void __launch_bounds__(kBlock) k_make_innerh(const InnerNode* __restrict__ in, uint32_t n, InnerNodeH* __restrict__ out) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const InnerNode a = in[i];
+    InnerNodeH o;
+    for (int k = 0; k < 3; k++) {
+        o.lo[k][0] = f32_down(a.lo0[k]); o.hi[k][0] = f32_up(a.hi0[k]);
+        o.lo[k][1] = f32_down(a.lo1[k]); o.hi[k][1] = f32_up(a.hi1[k]);
     }
     o.ref0 = a.ref0; o.ref1 = a.ref1; o.axis = a.axis; o.pad_ = 0;
     out[i] = o;

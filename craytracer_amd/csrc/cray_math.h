@@ -281,8 +281,8 @@ CRAY_HD float f32_up(double x) {
     return (double)f < x ? nextafterf(f, __builtin_huge_valf()) : f;
 #endif
 }
-struct HybRay {
-    float o[3], r[3];
+struct HybRay {   // (scalars, not arrays: a struct of arrays in a kernel's lane state gets promoted to LDS by the compiler)
+    float ox, oy, oz, rx, ry, rz;
     float a;   // NaN: this ray is outside the certified range, every decision is resolved exactly
 };
 constexpr float kHybC = 0x1p-21f;     // 8u
@@ -296,8 +296,8 @@ CRAY_HD bool hyb_scene_ok(const double* root_lo, const double* root_hi) {  // ev
 }
 CRAY_HD HybRay hyb_ray(vec3 o, vec3 d, vec3 rd, bool fast_div) {
     HybRay h;
-    h.o[0] = (float)o.x; h.o[1] = (float)o.y; h.o[2] = (float)o.z;
-    h.r[0] = (float)rd.x; h.r[1] = (float)rd.y; h.r[2] = (float)rd.z;
+    h.ox = (float)o.x; h.oy = (float)o.y; h.oz = (float)o.z;
+    h.rx = (float)rd.x; h.ry = (float)rd.y; h.rz = (float)rd.z;
     const double ax = fabs(d.x), ay = fabs(d.y), az = fabs(d.z);
     const bool ok = fast_div && ax >= 0x1p-30 && ax <= 0x1p30 && ay >= 0x1p-30 && ay <= 0x1p30 && az >= 0x1p-30 && az <= 0x1p30 &&
                     fabs(o.x) <= 0x1p40 && fabs(o.y) <= 0x1p40 && fabs(o.z) <= 0x1p40;
@@ -314,15 +314,11 @@ CRAY_HD void hyb_tmax(double t, float& t_lo, float& t_hi) {
     t_hi = ok ? x * (1.0f + 0x1p-22f) : __builtin_huge_valf();
 }
 CRAY_HD float hyb_key(const float* lo, const float* hi, const HybRay& h) {
-    float tmin = -__builtin_huge_valf(), tmax = __builtin_huge_valf();
-#ifdef __HIP_DEVICE_COMPILE__
-#pragma unroll
-#endif
-    for (int k = 0; k < 3; k++) {
-        const float t0 = (lo[k] - h.o[k]) * h.r[k], t1 = (hi[k] - h.o[k]) * h.r[k];
-        tmin = fmaxf(tmin, fminf(t0, t1));
-        tmax = fminf(tmax, fmaxf(t0, t1));
-    }
+    const float ax = (lo[0] - h.ox) * h.rx, bx = (hi[0] - h.ox) * h.rx;
+    const float ay = (lo[1] - h.oy) * h.ry, by = (hi[1] - h.oy) * h.ry;
+    const float az = (lo[2] - h.oz) * h.rz, bz = (hi[2] - h.oz) * h.rz;
+    const float tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
     const float e0 = fmaf(kHybC, fabsf(tmin), h.a), e1 = fmaf(kHybC, fabsf(tmax), h.a);
     const float tl = tmin - e0, th = tmin + e0, xl = tmax - e1, xh = tmax + e1;
     float kc = __builtin_nanf("");
@@ -331,12 +327,50 @@ CRAY_HD float hyb_key(const float* lo, const float* hi, const HybRay& h) {
     if (tl > xh || xh < 0.0f) kc = __builtin_huge_valf();
     return kc;
 }
-CRAY_HD int hyb_status(float kc, float a, float t_lo, float t_hi) {
+CRAY_HD int hyb_status(float kc, float a, float t_lo, float t_hi) {   // a popped entry against the current ray.tmax; no branches
     const float m = fabsf(kc), e = fmaf(kHybC, m, a);
-    if (kc == __builtin_huge_valf()) return kHybCull;
-    if (m + e < t_lo) return kHybVisit;
-    if (kc > 0.0f && m - e >= t_hi) return kHybCull;
-    return kHybResolve;
+    const bool visit = m + e < t_lo;
+    const bool cull = kc == __builtin_huge_valf() || (kc > 0.0f && m - e >= t_hi);
+    return cull ? kHybCull : (visit ? kHybVisit : kHybResolve);
+}
+
+// Both children of a node at once, as the kernel evaluates them: the record holds the two children's bounds interleaved
+// (InnerNodeH: lo[axis][child], hi[axis][child]), so the slab arithmetic runs on float2 = one packed instruction (v_pk_add_f32,
+// v_pk_mul_f32, v_pk_fma_f32) for both boxes.  Same classification as hyb_key + hyb_status, fused: the enclosure ends are the
+// very values hyb_status would recompute from kc.
+typedef float hyb_f2 __attribute__((ext_vector_type(2)));
+struct HybNode {
+    int s[2];      // kHybVisit / kHybCull / kHybResolve of child 0 / 1 against [t_lo, t_hi]
+    float kc[2];   // encoded key estimates (what a deferred child carries on the stack)
+};
+// (the ray's f32 view as seven scalars: the kernel keeps them in registers, an aggregate argument makes the compiler build it in LDS)
+CRAY_HD HybNode hyb_node(hyb_f2 lox, hyb_f2 loy, hyb_f2 loz, hyb_f2 hix, hyb_f2 hiy, hyb_f2 hiz, float h_ox, float h_oy, float h_oz,
+                         float h_rx, float h_ry, float h_rz, float h_a, float t_lo, float t_hi) {
+    const hyb_f2 ax = (lox - h_ox) * h_rx, bx = (hix - h_ox) * h_rx;
+    const hyb_f2 ay = (loy - h_oy) * h_ry, by = (hiy - h_oy) * h_ry;
+    const hyb_f2 az = (loz - h_oz) * h_rz, bz = (hiz - h_oz) * h_rz;
+    HybNode out;
+#ifdef __HIP_DEVICE_COMPILE__
+#pragma unroll
+#endif
+    for (int c = 0; c < 2; c++) {
+        const float tmin = fmaxf(fmaxf(fminf(ax[c], bx[c]), fminf(ay[c], by[c])), fminf(az[c], bz[c]));
+        const float tmax = fminf(fminf(fmaxf(ax[c], bx[c]), fmaxf(ay[c], by[c])), fmaxf(az[c], bz[c]));
+        const float e0 = fmaf(kHybC, fabsf(tmin), h_a), e1 = fmaf(kHybC, fabsf(tmax), h_a);
+        const float tl = tmin - e0, th = tmin + e0, xl = tmax - e1, xh = tmax + e1;
+        const bool ordered = th <= xl && xl > kHybEpsUp;           // certainly tmin <= tmax and tmax > EPS
+        const bool front = tl > kHybEpsUp;                          // certainly tmin > EPS
+        const bool inside = th <= 0.0f && xl >= 0.0f;               // certainly tmin <= 0 <= tmax
+        const bool miss = tl > xh || xh < 0.0f;                     // certainly tmin > tmax, or tmax < 0
+        const float upper = inside ? -3e38f : (front ? th : xh);    // key <= upper when `inside` or `ordered`
+        const bool visit = (inside || ordered) && upper < t_lo;     // (t_lo = -inf for a ray.tmax that is NaN or not positive)
+        const bool cull = miss || (front && tl >= t_hi);
+        out.s[c] = cull ? kHybCull : (visit ? kHybVisit : kHybResolve);
+        float kc = ordered ? (front ? tmin : -tmax) : __builtin_nanf("");
+        kc = inside ? -1e-30f : kc;
+        out.kc[c] = miss ? __builtin_huge_valf() : kc;
+    }
+    return out;
 }
 
 }  // namespace cray

@@ -1,0 +1,83 @@
+"""The opt-in certified f32 culling of the exact traversal (CRAY_HYBRID=1): 64-B f32 node records decide what
+they can certify, everything else is retaken from the f64 record.  It must change nothing: hits, distances and the node /
+primitive counters against the oracle, films bit for bit against the default (f64 records) context."""
+import numpy as np
+import pytest
+
+from craytracer_amd import backend
+from oracle import oracle_lib as ol
+from tests.parity_util import small_scenes, random_rays
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ctxs():
+    import os
+    old = os.environ.get('CRAY_HYBRID')
+    os.environ['CRAY_HYBRID'] = '1'          # read when the context is created
+    hyb = backend.Context(0)
+    os.environ['CRAY_HYBRID'] = '0'
+    ref = backend.Context(0)
+    if old is None:
+        del os.environ['CRAY_HYBRID']
+    else:
+        os.environ['CRAY_HYBRID'] = old
+    yield hyb, ref
+    hyb.close()
+    ref.close()
+
+
+@pytest.mark.parametrize('name', [n for n, _ in small_scenes()])
+def test_hybrid_traversal_is_the_reference_traversal(ctxs, name):
+    hyb, _ = ctxs
+    sc = dict(small_scenes())[name]
+    dev = hyb.upload(backend.HostScene(sc))
+    orc = ol.OracleScene(sc)
+    rays = random_rays(orc, 4000, seed=21)
+    # origins exactly on bounding planes, axis-parallel directions: what the f32 side must hand to the exact path
+    nodes, _ = orc.bvh()
+    rng = np.random.default_rng(3)
+    pick = nodes[rng.integers(0, len(nodes), 500)]
+    pts = np.where(rng.random((500, 3)) < 0.5, pick['bmin'], pick['bmax'])
+    pts = pts[np.all(np.abs(pts) < 1e6, axis=1)]
+    extra = np.zeros((len(pts), 7))
+    extra[:, :3] = pts
+    d = rng.normal(size=(len(pts), 3))
+    d[rng.random(len(pts)) < 0.3, 0] = 0.0
+    extra[:, 3:6] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    extra[:, 6] = np.where(rng.random(len(pts)) < 0.5, np.inf, rng.uniform(1e-3, 10.0, len(pts)))
+    rays = np.concatenate([rays, extra])
+    g, gst = dev.trace(rays)
+    o, ost = orc.trace(rays)
+    assert np.array_equal(g['hit'], o['hit'])
+    h = o['hit'] != 0
+    assert np.array_equal(g['prim'][h], o['prim'][h])
+    assert np.array_equal(g['t'][h], o['t'][h])
+    assert gst['closest_nodes'] == ost['closest_nodes'] and gst['closest_prims'] == ost['closest_prims']
+    ga, gast = dev.trace(rays, any_hit=True)
+    oa, oast = orc.trace(rays, any_hit=True)
+    assert np.array_equal(ga['hit'], oa['hit'])
+    assert gast['shadow_nodes'] == oast['shadow_nodes'] and gast['shadow_prims'] == oast['shadow_prims']
+    # the timed kernels (no counting) find the same hits
+    gt, _ = dev.trace(rays, timed=True)
+    assert np.array_equal(gt['prim'], g['prim']) and np.array_equal(gt['t'], g['t'])
+    dev.close()
+
+
+@pytest.mark.parametrize('name', ['cornell', 'dragon', 'staircase'])
+def test_hybrid_film_is_the_default_film(ctxs, name):
+    hyb, ref = ctxs
+    sc = dict(small_scenes())[name]
+    host = backend.HostScene(sc)
+    dh, dr = hyb.upload(host), ref.upload(host)
+    fh, sh = dh.render(seed=4)
+    fr, sr = dr.render(seed=4)
+    assert np.array_equal(fh, fr)
+    assert sh['closest_rays'] == sr['closest_rays'] and sh['shadow_rays'] == sr['shadow_rays']
+    fh2, sh2 = dh.render(seed=4, count_traversal=True)
+    fr2, sr2 = dr.render(seed=4, count_traversal=True)
+    assert np.array_equal(fh2, fr) and np.array_equal(fr2, fr)
+    for k in ('closest_nodes', 'closest_prims', 'shadow_nodes', 'shadow_prims'):
+        assert sh2[k] == sr2[k], k
+    dh.close(); dr.close()
