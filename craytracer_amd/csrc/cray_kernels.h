@@ -555,45 +555,43 @@ __device__ __forceinline__ void trace_body32(const DevScene& sc, const PathState
                 need_pop = true;
             }
         } else if (active) {
-            const uint32_t first = ref_leaf_first(cur), count = ref_leaf_count(cur);
-            for (uint32_t k = 0; k < count; k++) {
-                if (k > 0) {
-                    const float4* rec = reinterpret_cast<const float4*>(sc.slots32 + first + k);
-                    r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
-                }
-                const uint32_t s_prim = __float_as_uint(r2.y), s_kind = __float_as_uint(r2.z);
-                if (s_kind == CRAY_SHAPE_TRIANGLE) {
-                    if ((int32_t)s_prim == skip) continue;
-                    // Moller-Trumbore as in shape.rs:216-262, in f32
-                    const float v0[3] = {r0.x, r0.y, r0.z}, e1[3] = {r0.w, r1.x, r1.y}, e2[3] = {r1.z, r1.w, r2.x};
-                    const float P[3] = {d[1] * e2[2] - d[2] * e2[1], d[2] * e2[0] - d[0] * e2[2], d[0] * e2[1] - d[1] * e2[0]};
-                    const float det = P[0] * e1[0] + P[1] * e1[1] + P[2] * e1[2];
-                    if (det == 0.0f) continue;
+            // one slot per iteration, as in trace_body: the remaining slots of a leaf are fetched by the next iterations' record fetch
+            const uint32_t s_prim = __float_as_uint(r2.y), s_kind = __float_as_uint(r2.z);
+            if (s_kind == CRAY_SHAPE_TRIANGLE) {
+                // Moller-Trumbore as in shape.rs:216-262, in f32
+                const float v0[3] = {r0.x, r0.y, r0.z}, e1[3] = {r0.w, r1.x, r1.y}, e2[3] = {r1.z, r1.w, r2.x};
+                const float P[3] = {d[1] * e2[2] - d[2] * e2[1], d[2] * e2[0] - d[0] * e2[2], d[0] * e2[1] - d[1] * e2[0]};
+                const float det = P[0] * e1[0] + P[1] * e1[1] + P[2] * e1[2];
+                if ((int32_t)s_prim != skip && det != 0.0f) {
                     const float inv = 1.0f / det;
                     const float T[3] = {o[0] - v0[0], o[1] - v0[1], o[2] - v0[2]};
                     const float u = (P[0] * T[0] + P[1] * T[1] + P[2] * T[2]) * inv;
-                    if (!(u >= 0.0f && u <= 1.0f)) continue;
                     const float Q[3] = {T[1] * e1[2] - T[2] * e1[1], T[2] * e1[0] - T[0] * e1[2], T[0] * e1[1] - T[1] * e1[0]};
                     const float v = (Q[0] * d[0] + Q[1] * d[1] + Q[2] * d[2]) * inv;
-                    if (!(v >= 0.0f && u + v <= 1.0f)) continue;
                     const float t = (Q[0] * e2[0] + Q[1] * e2[1] + Q[2] * e2[2]) * inv;
-                    if (t > t_lo && t < tmax) {
-                        if (CRAY_ANY_LANE) { occluded = true; break; }
-                        tmax = t; ray.tmax = (double)t;
-                        hit_t = (double)t; hit_u = (double)u; hit_v = (double)v; hit_prim = (int32_t)s_prim;
+                    if (u >= 0.0f && u <= 1.0f && v >= 0.0f && u + v <= 1.0f && t > t_lo && t < tmax) {
+                        if (CRAY_ANY_LANE) occluded = true;
+                        else {
+                            tmax = t; ray.tmax = (double)t;
+                            hit_t = (double)t; hit_u = (double)u; hit_v = (double)v; hit_prim = (int32_t)s_prim;
+                        }
                     }
-                } else {
-                    const cray_prim& pr = sc.prims[s_prim];
-                    const bool hit = s_kind == CRAY_SHAPE_SPHERE ? sphere_hit(sc.spheres[pr.shape], ray, CRAY_ANY_LANE, nullptr)
-                                                                 : disk_hit(sc.disks[pr.shape], ray, CRAY_ANY_LANE, nullptr);
-                    if (hit) {
-                        if (CRAY_ANY_LANE) { occluded = true; break; }
+                }
+            } else {
+                const cray_prim& pr = sc.prims[s_prim];
+                const bool hit = s_kind == CRAY_SHAPE_SPHERE ? sphere_hit(sc.spheres[pr.shape], ray, CRAY_ANY_LANE, nullptr)
+                                                             : disk_hit(sc.disks[pr.shape], ray, CRAY_ANY_LANE, nullptr);
+                if (hit) {
+                    if (CRAY_ANY_LANE) occluded = true;
+                    else {
                         hit_t = ray.tmax; hit_prim = (int32_t)s_prim;
                         tmax = __double2float_ru(ray.tmax);
                     }
                 }
             }
-            if (CRAY_ANY_LANE && occluded) finished = true; else need_pop = true;
+            if (CRAY_ANY_LANE && occluded) finished = true;
+            else if (ref_leaf_count(cur) > 1) cur += 7u;
+            else need_pop = true;
         }
         if (active && need_pop) {
             for (;;) {
