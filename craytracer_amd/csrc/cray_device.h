@@ -21,6 +21,10 @@ constexpr int kStackDepth = 96;
 #ifndef CRAY_SHADE_TILE
 #define CRAY_SHADE_TILE 2048
 #endif
+#ifndef CRAY_SHADE_LDS_TABLES
+#define CRAY_SHADE_LDS_TABLES 40960
+#endif
+constexpr uint32_t kShadeLdsTables = CRAY_SHADE_LDS_TABLES;  // LDS bytes k_shade may fill with the small shading tables (2 blocks of 16 + 40 KB per CU)
 constexpr uint32_t kShadeTile = CRAY_SHADE_TILE;  // paths per block-level queue flush in k_shade (8 x 256)
 #ifndef CRAY_LDS_STACK
 #define CRAY_LDS_STACK 12
@@ -119,6 +123,8 @@ struct DevScene {
     const cray_image* images;
     const uint8_t* pool;
     const double* gamma_lut;  // (c/255)^2.2 for c in 0..255 (Color::from_rgb, color.rs:39-46)
+    uint32_t n_materials, n_bxdfs, n_textures, n_images, pad_tab_;
+    uint32_t shade_tables_bytes;  // > 0: materials + bxdfs + textures + lights + light tables fit k_shade's LDS staging area (bytes)
     // lights
     const DevLight* lights;
     const double* light_cdf;

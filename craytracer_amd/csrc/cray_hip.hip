@@ -242,6 +242,8 @@ void fill_stats(const Counters& h, cray_stats* st) {
                 100.0 * g[2] / g[0], g[2] ? (double)g[3] / g[2] : 0.0, g[4], g[4] ? (double)g[5] / g[4] : 0.0);
         fprintf(stderr, "diag %s: iterations with a lane at a leaf %.1f%%, at a sphere / disk slot %.1f%% (%.2f lanes), at a leaf of several slots %.1f%%\n",
                 a ? "any" : "closest", 100.0 * g[10] / g[0], 100.0 * g[11] / g[0], (double)g[13] / g[0], 100.0 * g[12] / g[0]);
+        fprintf(stderr, "diag %s: pop loop entered in %.1f%% of the iterations, %.2f trips per entry (the wave runs the maximum over its lanes)\n",
+                a ? "any" : "closest", 100.0 * g[15] / g[0], g[15] ? (double)g[14] / g[15] : 0.0);
     }
 #endif
 }
@@ -792,6 +794,17 @@ extern "C" int cray_scene_upload(cray_ctx* c, const cray_flat_scene* f, cray_sce
     if (!e) e = upload(s, f->first_equal_light, (size_t)f->n_lights, &d.first_equal_light);
     if (!e) e = upload(s, g_sobol_table, (size_t)CRAY_SOBOL_SETS * CRAY_SOBOL_BITS * 4, &d.sobol);
     if (e) { cray_scene_free(s); return e; }
+    // k_shade walks materials -> lobes -> textures and the light tables by dependent loads: staged in LDS when they fit
+    d.n_materials = (uint32_t)mats.size(); d.n_bxdfs = f->n_bxdfs; d.n_textures = f->n_textures; d.n_images = f->n_images;
+    {
+        auto pad16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
+        const size_t need = pad16(mats.size() * sizeof(cray_material)) + pad16((size_t)f->n_bxdfs * sizeof(cray_bxdf)) +
+                            pad16((size_t)f->n_textures * sizeof(cray_texture)) + pad16((size_t)f->n_lights * sizeof(DevLight)) +
+                            pad16((size_t)f->n_lights * 8) + pad16((size_t)f->n_lights * 4) +
+                            pad16((size_t)f->n_images * sizeof(cray_image)) + 256 * 8;   // (the last two only where textures read images)
+        const char* ev = getenv("CRAY_SHADE_LDS");   // experiments: 0 keeps the tables in global memory
+        d.shade_tables_bytes = (need <= kShadeLdsTables && !(ev && ev[0] == '0')) ? (uint32_t)need : 0u;
+    }
     // what this scene can make k_shade do -> the leanest instantiation that covers it
     uint32_t feat = 0;
     for (uint32_t i = 0; i < f->n_textures; i++)
@@ -902,21 +915,23 @@ int ensure_fast_layout(cray_ctx* c, cray_scene* s) {
 template <int I>
 struct ShadeLaunch {
     template <class... A>
-    static void go(int variant, int mode, dim3 grid, hipStream_t st, A... args) {
+    static void go(int variant, int mode, bool lds_tables, dim3 grid, hipStream_t st, A... args) {
         if (mode != 0) {  // the selectable alternatives of the reference (simple integrator, uniform sampler): all-features kernel
             if (mode == kModeSimple) hipLaunchKernelGGL((k_shade<SF_ALL, kModeSimple>), grid, dim3(kBlock), 0, st, args...);
             else if (mode == kModeUniform) hipLaunchKernelGGL((k_shade<SF_ALL, kModeUniform>), grid, dim3(kBlock), 0, st, args...);
             else hipLaunchKernelGGL((k_shade<SF_ALL, kModeSimple | kModeUniform>), grid, dim3(kBlock), 0, st, args...);
             return;
         }
-        if (variant == I) hipLaunchKernelGGL((k_shade<kShadeVariants[I], 0>), grid, dim3(kBlock), 0, st, args...);
-        else ShadeLaunch<I + 1>::go(variant, mode, grid, st, args...);
+        if (variant == I) {
+            if (lds_tables) hipLaunchKernelGGL((k_shade<kShadeVariants[I], kModeLdsTables>), grid, dim3(kBlock), 0, st, args...);
+            else hipLaunchKernelGGL((k_shade<kShadeVariants[I], 0>), grid, dim3(kBlock), 0, st, args...);
+        } else ShadeLaunch<I + 1>::go(variant, mode, lds_tables, grid, st, args...);
     }
 };
 template <>
 struct ShadeLaunch<kNumShadeVariants> {
     template <class... A>
-    static void go(int, int, dim3, hipStream_t, A...) {}
+    static void go(int, int, bool, dim3, hipStream_t, A...) {}
 };
 
 int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const PassPlan& pp, EventTimer* tm) {
@@ -968,7 +983,7 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
         HIP_TRY(hipMemsetAsync(&ctr->n_shadow, 0, sizeof(unsigned int), st));
         HIP_TRY(hipMemsetAsync(&ctr->trace_head, 0, sizeof(unsigned int), st));
         if (tm) { int e = tm->begin(FAM_SHADE); if (e) return e; }
-        ShadeLaunch<0>::go(s->shade_variant, mode, dim3(g_shade), st, d, c->ps, q, nq, n_paths, b, spp_pass, pp.s_lo, q_next, n_next,
+        ShadeLaunch<0>::go(s->shade_variant, mode, d.shade_tables_bytes != 0, dim3(g_shade), st, d, c->ps, q, nq, n_paths, b, spp_pass, pp.s_lo, q_next, n_next,
                            c->shadow_queue, &ctr->n_shadow, ctr, trace_all, uni_nx, uni_ny);
         if (tm) { int e = tm->end(); if (e) return e; }
 

@@ -571,6 +571,44 @@ extern "C" void cray_host_sincos(double x, double* s, double* c) {
     if (c) *c = cv;
 }
 
+extern "C" uint64_t cray_host_sincos_fast_check(const double* x, uint64_t n, double* stats /* [3] */) {
+    using namespace cray;
+    uint64_t bad = 0, slow = 0;
+    double worst = 0.0;   // largest |short evaluation - double-double evaluation| / |value| seen, in units of 2^-64 (= kSinCosEps)
+    for (uint64_t i = 0; i < n; i++) {
+        double s1, c1, s2, c2;
+        sincos_cr(x[i], s1, c1);
+        sincos_cr_dd(x[i], s2, c2);
+        if (memcmp(&s1, &s2, 8) != 0 || memcmp(&c1, &c2, 8) != 0) bad++;
+        const SinCosArg A = sincos_reduce(x[i]);
+        double sv, cv;
+        if (!sincos_fast_core(A, sv, cv)) slow++;
+        // deviation of the candidates from the double-double values (both as hi + lo pairs)
+        double s_hi, s_lo, c_hi, c_lo;
+        sincos_fast_parts(A, s_hi, s_lo, c_hi, c_lo);
+        const dd l = A.l, S = A.S, C = A.C;
+        (void)l; (void)S; (void)C;
+        // recompute the double-double pair through the reference evaluation's own arithmetic
+        const dd l2 = dd_mul(A.l, A.l);
+        const double ts = -0x1.a01a01a01a01ap-13 + l2.hi * (0x1.71de3a556c734p-19 + l2.hi * -0x1.ae64567f544e4p-26);
+        const double tc = -0x1.6c16c16c16c17p-10 + l2.hi * (0x1.a01a01a01a01ap-16 + l2.hi * (-0x1.27e4fb7789f5cp-22 + l2.hi * 0x1.1eed8eff8d898p-29));
+        dd ps = dd_add(dd{0x1.1111111111111p-7, 0x1.1111111111111p-63}, dd_mul_d(l2, ts));
+        ps = dd_add(dd{-0x1.5555555555555p-3, -(0x1.5555555555555p-57)}, dd_mul(l2, ps));
+        ps = dd_add(dd{1.0, 0.0}, dd_mul(l2, ps));
+        const dd sl = dd_mul(A.l, ps);
+        dd pc = dd_add(dd{0x1.5555555555555p-5, 0x1.5555555555555p-59}, dd_mul_d(l2, tc));
+        pc = dd_add(dd{-0.5, 0.0}, dd_mul(l2, pc));
+        const dd cl = dd_add(dd{1.0, 0.0}, dd_mul(l2, pc));
+        const dd sr = dd_add(dd_mul(A.S, cl), dd_mul(A.C, sl));
+        const dd cr = dd_add(dd_mul(A.C, cl), dd_neg(dd_mul(A.S, sl)));
+        const double ds = fabs((s_hi - sr.hi) + (s_lo - sr.lo)), dc = fabs((c_hi - cr.hi) + (c_lo - cr.lo));
+        if (sr.hi != 0.0) worst = fmax(worst, ds / fabs(sr.hi) * 0x1p64);
+        if (cr.hi != 0.0) worst = fmax(worst, dc / fabs(cr.hi) * 0x1p64);
+    }
+    if (stats) { stats[0] = (double)slow; stats[1] = worst; stats[2] = (double)n; }
+    return bad;
+}
+
 extern "C" uint64_t cray_host_div_fast_mismatches(const double* a, const double* d, uint64_t n) {
     uint64_t bad = 0;
     for (uint64_t i = 0; i < n; i++) {

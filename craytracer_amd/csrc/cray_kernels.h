@@ -349,8 +349,15 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
         }
 #pragma clang diagnostic pop
         // ---- pop: a deferred child is re-tested against the current (shrunken) ray.tmax
+#ifdef CRAY_TRACE_DIAG
+        dg[15] += __any(active && need_pop) ? 1 : 0;
+        unsigned int trips = 0;
+#endif
         if (active && need_pop) {
             for (;;) {
+#ifdef CRAY_TRACE_DIAG
+                trips++;
+#endif
                 if (sp == 0) { finished = true; break; }
                 --sp;
                 if (COUNT && ANY) n_nodes += 1;
@@ -365,6 +372,10 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
                 }
             }
         }
+#ifdef CRAY_TRACE_DIAG
+        for (int o_ = 32; o_; o_ >>= 1) { const unsigned int t_ = (unsigned int)__shfl_xor((int)trips, o_); trips = t_ > trips ? t_ : trips; }
+        dg[14] += trips;   // trips of the pop loop as the wave runs it: the maximum over its lanes
+#endif
         if (active && finished) {
             pending = CRAY_ANY_LANE ? !occluded : true;
             active = false;
@@ -717,7 +728,7 @@ __device__ __forceinline__ void queue_push(uint32_t* __restrict__ q, unsigned in
 //      bit 1: UniformSampler (src/sampling.rs:154-194) instead of SobolSampler; uni_nx / uni_ny are its two slot counts.
 // The reference's `main` runs mode 0 (path integrator + Sobol, craytracer.rs:159-160, 361); the others are its selectable
 // alternatives and run on the all-features instantiation only.
-enum { kModeSimple = 1, kModeUniform = 2 };
+enum { kModeSimple = 1, kModeUniform = 2, kModeLdsTables = 4 };
 template <uint32_t F, int MODE = 0>
 __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
                                                   const unsigned int* __restrict__ n_ptr, uint32_t n_fixed, uint32_t bounce,
@@ -733,6 +744,36 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
     // MI355X_MICROARCH.md "dequeue") was half of this kernel's time: 1 M atomics per 33 M-path launch.
     __shared__ uint32_t l_shadow[kShadeTile], l_next[kShadeTile];
     __shared__ unsigned int c_shadow, c_next, c_skip, c_hit, g_shadow, g_next;
+    // The small shading tables (materials -> lobes -> textures, lights and their CDF) are walked by DEPENDENT loads: five to eight
+    // round trips per path, each a trip to L2 for a wave that has only one other wave to hide behind (2 waves / SIMD).  When the
+    // runtime found that they fit, every block copies them into LDS once and the walk reads LDS (through generic pointers).
+    // (its own instantiation, MODE & kModeLdsTables: generic pointers make every table access a flat load, which costs the scenes
+    // whose tables do not fit 7 % of this kernel)
+    constexpr bool kLdsTables = (MODE & kModeLdsTables) != 0;
+    __shared__ alignas(16) unsigned char l_tab[kLdsTables ? kShadeLdsTables : 16u];
+    if (kLdsTables) {
+        uint32_t off = 0;
+        auto stage = [&](const void* src, uint32_t bytes) -> const void* {
+            const uint32_t* s4 = static_cast<const uint32_t*>(src);
+            uint32_t* d4 = reinterpret_cast<uint32_t*>(l_tab + off);
+            for (uint32_t w = threadIdx.x; w < bytes / 4; w += kBlock) d4[w] = s4[w];
+            const void* at = l_tab + off;
+            off += (bytes + 15u) & ~15u;
+            return at;
+        };
+        const uint32_t nl = sc.n_lights;
+        sc.materials = static_cast<const cray_material*>(stage(sc.materials, sc.n_materials * (uint32_t)sizeof(cray_material)));
+        sc.bxdfs = static_cast<const cray_bxdf*>(stage(sc.bxdfs, sc.n_bxdfs * (uint32_t)sizeof(cray_bxdf)));
+        sc.textures = static_cast<const cray_texture*>(stage(sc.textures, sc.n_textures * (uint32_t)sizeof(cray_texture)));
+        sc.lights = static_cast<const DevLight*>(stage(sc.lights, nl * (uint32_t)sizeof(DevLight)));
+        sc.light_cdf = static_cast<const double*>(stage(sc.light_cdf, nl * 8u));
+        sc.first_equal_light = static_cast<const int32_t*>(stage(sc.first_equal_light, nl * 4u));
+        if (CRAY_HAS(F, SF_TEX_IMAGE)) {   // image descriptors and the 8-bit -> linear table sit behind the texel fetch
+            sc.images = static_cast<const cray_image*>(stage(sc.images, sc.n_images * (uint32_t)sizeof(cray_image)));
+            sc.gamma_lut = static_cast<const double*>(stage(sc.gamma_lut, 256u * 8u));
+        }
+        __syncthreads();
+    }
     const uint32_t n_tiles = (n + kShadeTile - 1) / kShadeTile;
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
       if (threadIdx.x == 0) { c_shadow = 0; c_next = 0; c_skip = 0; c_hit = 0; }

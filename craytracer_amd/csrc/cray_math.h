@@ -424,7 +424,14 @@ CRAY_HD dd dd_mul_d(dd a, double b) {
 }
 CRAY_HD dd dd_neg(dd a) { return dd{-a.hi, -a.lo}; }
 
-CRAY_HD void sincos_cr(double x, double& s_out, double& c_out) {
+// Argument reduction and table lookup shared by the two evaluations below: x = kq pi/2 +- (k/64 + l), |l| <= 2^-7 as a double-double,
+// S = sin(k/64), C = cos(k/64) as double-doubles.
+struct SinCosArg {
+    dd l, S, C;
+    bool neg;
+    int q;
+};
+CRAY_HD SinCosArg sincos_reduce(double x) {
     // pi/2 = P1 + P2 + P3 + P4; P1..P3 carry 33 significant bits, so k * Pi is exact for |k| < 2^20
     const double P1 = 0x1.921fb54400000p+0, P2 = 0x1.0b4611a600000p-34, P3 = 0x1.3198a2e000000p-69, P4 = 0x1.b839a252049c1p-104;
     const double kq = rint(x * 0x1.45f306dc9c883p-1);  // nearest multiple of pi/2
@@ -491,7 +498,15 @@ CRAY_HD void sincos_cr(double x, double& s_out, double& c_out) {
         {0x1.62cf49921ac79p-1, -0x1.edd9855b6241ap-55, 0x1.712046fa77678p-1, 0x1.425b0a5029c81p-55},
         {0x1.6888a4e134b2fp-1, -0x1.6b7d37644d5e6p-55, 0x1.6b898fa9efb5dp-1, 0x1.15ac786ccf4b2p-56},
         {0x1.6e2b77c40bde1p-1, -0x1.0e729857fad53p-56, 0x1.65dc1fdeb8cbap-1, -0x1.97c1b47337c77p-58}};
-    const dd S = dd{kTab[k][0], kTab[k][1]}, C = dd{kTab[k][2], kTab[k][3]};
+    SinCosArg out;
+    out.l = l; out.neg = neg; out.q = ((int)kq) & 3;
+    out.S = dd{kTab[k][0], kTab[k][1]}; out.C = dd{kTab[k][2], kTab[k][3]};
+    return out;
+}
+
+// sin(k/64 + l), cos(k/64 + l) in double-double (~2^-100), one final rounding each: the reference evaluation.
+CRAY_HD void sincos_dd_core(const SinCosArg& A, double& sv, double& cv) {
+    const dd l = A.l, S = A.S, C = A.C;
     const dd l2 = dd_mul(l, l);
     // sin(l)/l and cos(l): the two leading correction terms in double-double, the (tiny) tails in double
     const double ts = -0x1.a01a01a01a01ap-13 + l2.hi * (0x1.71de3a556c734p-19 + l2.hi * -0x1.ae64567f544e4p-26);       // -1/7! + l2/9! - l2^2/11!
@@ -505,9 +520,70 @@ CRAY_HD void sincos_cr(double x, double& s_out, double& c_out) {
     const dd cl = dd_add(dd{1.0, 0.0}, dd_mul(l2, pc));
     dd sr = dd_add(dd_mul(S, cl), dd_mul(C, sl));        // sin(h + l)
     const dd cr = dd_add(dd_mul(C, cl), dd_neg(dd_mul(S, sl)));
-    if (neg) sr = dd_neg(sr);
-    const double sv = sr.hi + sr.lo, cv = cr.hi + cr.lo;
-    const int q = ((int)kq) & 3;
+    sv = sr.hi + sr.lo;
+    cv = cr.hi + cr.lo;
+}
+
+// The same two values from a SHORT evaluation with a rounding test (Ziv's strategy): the leading terms exactly (two_prod / two_sum),
+// the small ones in plain f64.  With z = l^2, f = cos(l) - 1, g = sin(l)/l - 1:
+//     sin(h + l) = S.hi + C.hi l.hi + { e(C.hi l.hi) + S.lo + C.hi l.lo + C.lo l.hi + (C.hi l.hi) g + S.hi f },
+//     cos(h + l) = C.hi - S.hi l.hi + { ... - (S.hi l.hi) g + C.hi f }.
+// Error of the braces: three roundings at the magnitude of the last term (<= 2^-15 |S.hi|, |C.hi|) = 3 x 2^-68 relative to S.hi / C.hi,
+// the truncated series 2^-90, the neglected S.lo f, C.lo l.lo ... 2^-69; the result is >= |S.hi| / 2 (k >= 1; for k = 0 every term
+// scales with l).  So the candidate hi + lo is within 2^-65 |result| of the true value, and kSinCosEps = 2^-64 |hi| is a safe radius:
+// if RN(hi + (lo - eps)) == RN(hi + (lo + eps)) that IS the correctly rounded value, otherwise (2^-10 of the calls) the caller takes the
+// double-double evaluation.  tests/test_host_and_abi.py compares the two on 2 x 10^7 arguments and records the largest deviation seen.
+constexpr double kSinCosEps = 0x1p-64;
+CRAY_HD void sincos_fast_parts(const SinCosArg& A, double& s_hi, double& s_lo, double& c_hi, double& c_lo) {
+    const double lh = A.l.hi, ll = A.l.lo;
+    const dd zz = dd_two_prod(lh, lh);
+    const double z = zz.hi, zl = fma(2.0 * lh, ll, zz.lo);   // l^2 = z + zl
+    // f = -z/2 + z^2/24 - z^3/720 + z^4/40320 (+ the low part of the leading term), g = -z/6 + z^2/120 - z^3/5040
+    const double hf = -0.5 + z * (0x1.5555555555555p-5 + z * (-0x1.6c16c16c16c17p-10 + z * 0x1.a01a01a01a01ap-16));
+    const double f = fma(z, hf, -0.5 * zl);
+    const double g = z * (-0x1.5555555555555p-3 + z * (0x1.1111111111111p-7 + z * -0x1.a01a01a01a01ap-13));
+    const double Sh = A.S.hi, Sl = A.S.lo, Ch = A.C.hi, Cl = A.C.lo;
+    const dd ps = dd_two_prod(Ch, lh);
+    double ts = ps.lo + Sl;
+    ts += Ch * ll + Cl * lh;
+    ts = fma(ps.hi, g, ts);
+    ts = fma(Sh, f, ts);
+    const dd s1 = dd_two_sum(ps.hi, ts), s2 = dd_two_sum(Sh, s1.hi);
+    s_hi = s2.hi; s_lo = s2.lo + s1.lo;
+    const dd pc = dd_two_prod(-Sh, lh);
+    double tc = pc.lo + Cl;
+    tc -= Sh * ll + Sl * lh;
+    tc = fma(pc.hi, g, tc);
+    tc = fma(Ch, f, tc);
+    const dd c1 = dd_two_sum(pc.hi, tc), c2 = dd_two_sum(Ch, c1.hi);
+    c_hi = c2.hi; c_lo = c2.lo + c1.lo;
+}
+CRAY_HD bool sincos_fast_core(const SinCosArg& A, double& sv, double& cv) {
+    double s_hi, s_lo, c_hi, c_lo;
+    sincos_fast_parts(A, s_hi, s_lo, c_hi, c_lo);
+    const double se = kSinCosEps * fabs(s_hi), ce = kSinCosEps * fabs(c_hi);
+    const double sa = s_hi + (s_lo - se), sb = s_hi + (s_lo + se);
+    const double ca = c_hi + (c_lo - ce), cb = c_hi + (c_lo + ce);
+    sv = sa; cv = ca;
+    return sa == sb && ca == cb;
+}
+
+CRAY_HD void sincos_cr(double x, double& s_out, double& c_out) {
+    const SinCosArg A = sincos_reduce(x);
+    double sv, cv;
+    if (!sincos_fast_core(A, sv, cv)) sincos_dd_core(A, sv, cv);
+    if (A.neg) sv = -sv;
+    const int q = A.q;
+    s_out = q == 0 ? sv : (q == 1 ? cv : (q == 2 ? -sv : -cv));
+    c_out = q == 0 ? cv : (q == 1 ? -sv : (q == 2 ? -cv : sv));
+}
+// the double-double evaluation alone (what sincos_cr was before the short path; kept callable for the tests)
+CRAY_HD void sincos_cr_dd(double x, double& s_out, double& c_out) {
+    const SinCosArg A = sincos_reduce(x);
+    double sv, cv;
+    sincos_dd_core(A, sv, cv);
+    if (A.neg) sv = -sv;
+    const int q = A.q;
     s_out = q == 0 ? sv : (q == 1 ? cv : (q == 2 ? -sv : -cv));
     c_out = q == 0 ? cv : (q == 1 ? -sv : (q == 2 ? -cv : sv));
 }

@@ -47,6 +47,12 @@ void cray_host_scene_free(cray_host_scene* scene);
  * (src/sampling.rs:17-39), evaluated on the host by the very same code (cray_math.h). */
 void cray_host_sincos(double x, double* sin_out, double* cos_out);
 
+/* The short evaluation + rounding test of the sampling sin/cos (cray_math.h sincos_fast_core) against the double-double evaluation
+ * it falls back to: returns the number of arguments on which sincos_cr differs from the double-double result in any bit (must be 0);
+ * stats[0] = calls that took the fallback, stats[1] = largest deviation of the short evaluation's candidate from the double-double
+ * value, relative, in units of the test radius 2^-64 (must stay well below 1), stats[2] = n. */
+uint64_t cray_host_sincos_fast_check(const double* x, uint64_t n, double* stats);
+
 /* The exact FMA-based division the traversal kernel uses for (bound - origin) / direction
  * (cray_math.h div_fast): returns the number of i in [0,n) with div_fast(a[i], d[i], 1/d[i]) != a[i]/d[i]
  * bitwise, among the pairs that pass the range guard. */
