@@ -123,7 +123,8 @@ struct DevScene {
     const cray_image* images;
     const uint8_t* pool;
     const double* gamma_lut;  // (c/255)^2.2 for c in 0..255 (Color::from_rgb, color.rs:39-46)
-    uint32_t n_materials, n_bxdfs, n_textures, n_images, pad_tab_;
+    uint32_t n_materials, n_bxdfs, n_textures, n_images, n_spheres, n_disks;
+    uint32_t shade_stage_shapes, pad_tab_;   // the sphere / disk tables fit the staging area as well
     uint32_t shade_tables_bytes;  // > 0: materials + bxdfs + textures + lights + light tables fit k_shade's LDS staging area (bytes)
     // lights
     const DevLight* lights;

@@ -804,6 +804,10 @@ extern "C" int cray_scene_upload(cray_ctx* c, const cray_flat_scene* f, cray_sce
                             pad16((size_t)f->n_images * sizeof(cray_image)) + 256 * 8;   // (the last two only where textures read images)
         const char* ev = getenv("CRAY_SHADE_LDS");   // experiments: 0 keeps the tables in global memory
         d.shade_tables_bytes = (need <= kShadeLdsTables && !(ev && ev[0] == '0')) ? (uint32_t)need : 0u;
+        const size_t shapes = pad16((size_t)f->n_spheres * sizeof(cray_xf_shape)) + pad16((size_t)f->n_disks * sizeof(cray_xf_shape));
+        d.n_spheres = f->n_spheres; d.n_disks = f->n_disks;
+        d.shade_stage_shapes = (d.shade_tables_bytes && need + shapes <= kShadeLdsTables) ? 1u : 0u;
+        if (d.shade_stage_shapes) d.shade_tables_bytes += (uint32_t)shapes;
     }
     // what this scene can make k_shade do -> the leanest instantiation that covers it
     uint32_t feat = 0;

@@ -768,6 +768,10 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
         sc.lights = static_cast<const DevLight*>(stage(sc.lights, nl * (uint32_t)sizeof(DevLight)));
         sc.light_cdf = static_cast<const double*>(stage(sc.light_cdf, nl * 8u));
         sc.first_equal_light = static_cast<const int32_t*>(stage(sc.first_equal_light, nl * 4u));
+        if (CRAY_HAS(F, SF_HIT_SPHERE | SF_HIT_DISK | SF_AREA_SPHERE | SF_AREA_DISK) && sc.shade_stage_shapes) {   // hit / emitter transforms
+            sc.spheres = static_cast<const cray_xf_shape*>(stage(sc.spheres, sc.n_spheres * (uint32_t)sizeof(cray_xf_shape)));
+            sc.disks = static_cast<const cray_xf_shape*>(stage(sc.disks, sc.n_disks * (uint32_t)sizeof(cray_xf_shape)));
+        }
         if (CRAY_HAS(F, SF_TEX_IMAGE)) {   // image descriptors and the 8-bit -> linear table sit behind the texel fetch
             sc.images = static_cast<const cray_image*>(stage(sc.images, sc.n_images * (uint32_t)sizeof(cray_image)));
             sc.gamma_lut = static_cast<const double*>(stage(sc.gamma_lut, 256u * 8u));
