@@ -81,3 +81,30 @@ def test_hybrid_film_is_the_default_film(ctxs, name):
     for k in ('closest_nodes', 'closest_prims', 'shadow_nodes', 'shadow_prims'):
         assert sh2[k] == sr2[k], k
     dh.close(); dr.close()
+
+
+@pytest.mark.parametrize('name', ['test', 'staircase', 'dragon'])
+def test_shading_tables_in_lds_or_in_global_memory_same_film(name):
+    """k_shade has two instantiations: the small shading tables staged in LDS (when they fit) or read from global memory
+    (CRAY_SHADE_LDS=0 at upload forces the latter, which is what a scene with thousands of materials gets).  Same film, bit for bit."""
+    import os
+    sc = dict(small_scenes())[name]
+    ctx = backend.Context(0)
+    host = backend.HostScene(sc)
+    a = ctx.upload(host)
+    old = os.environ.get('CRAY_SHADE_LDS')
+    os.environ['CRAY_SHADE_LDS'] = '0'
+    try:
+        b = ctx.upload(host)
+    finally:
+        if old is None:
+            del os.environ['CRAY_SHADE_LDS']
+        else:
+            os.environ['CRAY_SHADE_LDS'] = old
+    fa, sa = a.render(seed=9)
+    fb, sb = b.render(seed=9)
+    assert np.array_equal(fa, fb)
+    assert sa['closest_rays'] == sb['closest_rays'] and sa['shadow_rays'] == sb['shadow_rays']
+    ref, _ = ol.OracleScene(sc).render(seed=9)
+    assert np.array_equal(fa, ref)
+    a.close(); b.close(); ctx.close()
