@@ -438,6 +438,8 @@ __global__ void __launch_bounds__(kBlock) k_make_slots(const uint32_t* __restric
             s.v0[0] = t.v0.x; s.v0[1] = t.v0.y; s.v0[2] = t.v0.z;
             s.e1[0] = t.e1.x; s.e1[1] = t.e1.y; s.e1[2] = t.e1.z;
             s.e2[0] = t.e2.x; s.e2[1] = t.e2.y; s.e2[2] = t.e2.z;
+        } else {
+            s.v0[0] = __longlong_as_double((long long)p.shape);   // the sphere / disk index, so that k_trace needs no prims[] lookup
         }
     }
     slots[j] = s;
@@ -620,6 +622,9 @@ extern "C" int cray_scene_upload(cray_ctx* c, const cray_flat_scene* f, cray_sce
                    (p.shape_kind != CRAY_SHAPE_SPHERE && p.shape_kind != CRAY_SHAPE_DISK)) {
             set_last_error("primitive %u: bad shape", pi);
             return CRAY_ERR_INVALID;
+        } else {
+            const uint64_t bits = p.shape;   // the sphere / disk index, so that k_trace needs no prims[] lookup
+            memcpy(&s.v0[0], &bits, 8);
         }
         return CRAY_OK;
     };

@@ -332,9 +332,9 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
                     }
                 }
             } else {
-                const cray_prim& pr = sc.prims[s_prim];
-                const bool hit = s_kind == CRAY_SHAPE_SPHERE ? sphere_hit(sc.spheres[pr.shape], ray, CRAY_ANY_LANE, nullptr)
-                                                             : disk_hit(sc.disks[pr.shape], ray, CRAY_ANY_LANE, nullptr);
+                const uint32_t shp = (uint32_t)__double2loint(r0.x);   // the slot of a sphere / disk carries its index (no prims[] hop)
+                const bool hit = s_kind == CRAY_SHAPE_SPHERE ? sphere_hit(sc.spheres[shp], ray, CRAY_ANY_LANE, nullptr)
+                                                             : disk_hit(sc.disks[shp], ray, CRAY_ANY_LANE, nullptr);
                 if (hit) {
                     if (CRAY_ANY_LANE) occluded = true;
                     else {
