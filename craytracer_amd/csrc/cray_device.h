@@ -48,7 +48,7 @@ struct alignas(128) InnerNode {
 static_assert(sizeof(InnerNode) == 128, "InnerNode must be one 128-B line");
 
 struct alignas(16) LeafSlot {
-    double v0[3], e1[3], e2[3];  // Shape::Triangle geometry (zeros for sphere / disk slots)
+    double v0[3], e1[3], e2[3];  // Shape::Triangle geometry; sphere / disk slots: zeros, and the shape index in the bits of v0[0]
     uint32_t prim;               // index into prims[]
     uint32_t kind;               // CRAY_SHAPE_*
 };
@@ -64,7 +64,7 @@ struct alignas(64) InnerNode32 {
 static_assert(sizeof(InnerNode32) == 64, "InnerNode32 is four 16-B loads");
 struct alignas(16) LeafSlot32 {
     float v0[3], e1[3], e2[3];
-    uint32_t prim, kind, pad_;
+    uint32_t prim, kind, shape;   // shape: index into spheres[] / disks[] for those kinds
 };
 static_assert(sizeof(LeafSlot32) == 48, "LeafSlot32 is three 16-B loads");
 

@@ -589,9 +589,9 @@ __device__ __forceinline__ void trace_body32(const DevScene& sc, const PathState
                     }
                 }
             } else {
-                const cray_prim& pr = sc.prims[s_prim];
-                const bool hit = s_kind == CRAY_SHAPE_SPHERE ? sphere_hit(sc.spheres[pr.shape], ray, CRAY_ANY_LANE, nullptr)
-                                                             : disk_hit(sc.disks[pr.shape], ray, CRAY_ANY_LANE, nullptr);
+                const uint32_t shp = __float_as_uint(r2.w);   // LeafSlot32::shape
+                const bool hit = s_kind == CRAY_SHAPE_SPHERE ? sphere_hit(sc.spheres[shp], ray, CRAY_ANY_LANE, nullptr)
+                                                             : disk_hit(sc.disks[shp], ray, CRAY_ANY_LANE, nullptr);
                 if (hit) {
                     if (CRAY_ANY_LANE) occluded = true;
                     else {
@@ -671,7 +671,9 @@ __global__ void __launch_bounds__(kBlock) k_make_slots32(const LeafSlot* __restr
     const LeafSlot a = in[i];
     LeafSlot32 o;
     for (int k = 0; k < 3; k++) { o.v0[k] = (float)a.v0[k]; o.e1[k] = (float)a.e1[k]; o.e2[k] = (float)a.e2[k]; }
-    o.prim = a.prim; o.kind = a.kind; o.pad_ = 0;
+    o.prim = a.prim; o.kind = a.kind;
+    o.shape = a.kind == CRAY_SHAPE_TRIANGLE ? 0u : (uint32_t)__double2loint(a.v0[0]);   // sphere / disk index (LeafSlot::v0[0] carries it as bits)
+    if (a.kind != CRAY_SHAPE_TRIANGLE) o.v0[0] = 0.f;
     out[i] = o;
 }
 
