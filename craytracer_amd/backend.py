@@ -80,7 +80,7 @@ ABI_SYMBOLS = ['cray_ctx_create', 'cray_ctx_destroy', 'cray_scene_upload', 'cray
                'cray_scene_device_bytes', 'cray_render', 'cray_render_params_default', 'cray_render_samples',
                'cray_trace', 'cray_last_error', 'cray_host_scene_new', 'cray_host_scene_flat',
                'cray_host_scene_build_seconds', 'cray_host_scene_free', 'cray_host_scene_new_on',
-               'cray_host_scene_bvh_seconds', 'cray_bvh_build_sah', 'cray_write_exr', 'cray_read_exr', 'cray_host_sincos', 'cray_host_div_fast_mismatches', 'cray_host_child_key_mismatches', 'cray_host_hyb_key_violations', 'cray_host_sincos_fast_check',
+               'cray_host_scene_bvh_seconds', 'cray_bvh_build_sah', 'cray_write_exr', 'cray_read_exr', 'cray_host_sincos', 'cray_host_div_fast_mismatches', 'cray_host_child_key_mismatches', 'cray_host_hyb_key_violations', 'cray_host_sincos_fast_check', 'cray_host_chacha_block', 'cray_host_independent_draws',
                'cray_cry_tokenize', 'cray_cry_free_tokens', 'cray_cry_parse_value', 'cray_cry_free_string',
                'cray_cry_parse_scene', 'cray_owned_scene_desc', 'cray_owned_scene_warnings', 'cray_owned_scene_free',
                'cray_scene_info', 'cray_comm_unique_id', 'cray_comm_init', 'cray_comm_rank', 'cray_comm_world_size',
@@ -177,6 +177,11 @@ def lib():
     L.cray_host_div_fast_mismatches.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     L.cray_host_child_key_mismatches.restype = C.c_uint64
     L.cray_host_child_key_mismatches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    if hasattr(L, 'cray_host_chacha_block'):
+        L.cray_host_chacha_block.restype = None
+        L.cray_host_chacha_block.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.cray_host_independent_draws.restype = None
+        L.cray_host_independent_draws.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]
     if hasattr(L, 'cray_host_sincos_fast_check'):
         L.cray_host_sincos_fast_check.restype = C.c_uint64
         L.cray_host_sincos_fast_check.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
@@ -378,6 +383,8 @@ class DeviceScene:
     #: integrator 'path' | 'simple' (src/simple_integrator.rs), uniform_sampler None | (nx, ny) (sampling.rs:154-194)
     integrator = 'path'
     uniform_sampler = None
+    #: True: IndependentSampler (sampling.rs:102-146; restated from rand 0.8.5's published algorithms, not pinned against the crate)
+    independent_sampler = False
     #: 'f64' (the reference's arithmetic) or 'f32' (fast mode: f32 traversal, NOT bit-exact; cray_render_params.precision)
     precision = 'f64'
 
@@ -388,6 +395,8 @@ class DeviceScene:
         p.precision = {'f64': 0, 'f32': 1}[self.precision]
         if self.uniform_sampler is not None:
             p.sampler, (p.uniform_nx, p.uniform_ny) = 1, self.uniform_sampler
+        elif self.independent_sampler:
+            p.sampler = 2
         p.seed, p.rank, p.world_size = seed, rank, world_size
         if sample_range is not None:
             p.sample_begin, p.sample_end = sample_range

@@ -928,6 +928,8 @@ struct ShadeLaunch {
         if (mode != 0) {  // the selectable alternatives of the reference (simple integrator, uniform sampler): all-features kernel
             if (mode == kModeSimple) hipLaunchKernelGGL((k_shade<SF_ALL, kModeSimple>), grid, dim3(kBlock), 0, st, args...);
             else if (mode == kModeUniform) hipLaunchKernelGGL((k_shade<SF_ALL, kModeUniform>), grid, dim3(kBlock), 0, st, args...);
+            else if (mode == kModeIndependent) hipLaunchKernelGGL((k_shade<SF_ALL, kModeIndependent>), grid, dim3(kBlock), 0, st, args...);
+            else if (mode == (kModeSimple | kModeIndependent)) hipLaunchKernelGGL((k_shade<SF_ALL, kModeSimple | kModeIndependent>), grid, dim3(kBlock), 0, st, args...);
             else hipLaunchKernelGGL((k_shade<SF_ALL, kModeSimple | kModeUniform>), grid, dim3(kBlock), 0, st, args...);
             return;
         }
@@ -953,8 +955,9 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
 
     if (tm) { int e = tm->begin(FAM_OTHER); if (e) return e; }
     const uint32_t uni_nx = prm.sampler == CRAY_SAMPLER_UNIFORM ? prm.uniform_nx : 0u, uni_ny = prm.sampler == CRAY_SAMPLER_UNIFORM ? prm.uniform_ny : 0u;
-    const int mode = (prm.integrator == CRAY_INTEGRATOR_SIMPLE ? kModeSimple : 0) | (uni_nx ? kModeUniform : 0);
-    hipLaunchKernelGGL(k_raygen, dim3(grid_for(c, n_paths, 8)), dim3(kBlock), 0, st, d, c->ps, c->pix_list, pp.px0, n_paths, spp_pass, pp.s_lo, prm.seed, uni_nx, uni_ny);
+    const uint32_t independent = prm.sampler == CRAY_SAMPLER_INDEPENDENT ? 1u : 0u;
+    const int mode = (prm.integrator == CRAY_INTEGRATOR_SIMPLE ? kModeSimple : 0) | (uni_nx ? kModeUniform : 0) | (independent ? kModeIndependent : 0);
+    hipLaunchKernelGGL(k_raygen, dim3(grid_for(c, n_paths, 8)), dim3(kBlock), 0, st, d, c->ps, c->pix_list, pp.px0, n_paths, spp_pass, pp.s_lo, prm.seed, uni_nx, uni_ny, independent);
     if (tm) { int e = tm->end(); if (e) return e; }
 
     // Launch sequence of a pass.  The shadow rays of bounce b and the path segments of bounce b+1 both depend on
@@ -993,7 +996,7 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
         HIP_TRY(hipMemsetAsync(&ctr->trace_head, 0, sizeof(unsigned int), st));
         if (tm) { int e = tm->begin(FAM_SHADE); if (e) return e; }
         ShadeLaunch<0>::go(s->shade_variant, mode, d.shade_tables_bytes != 0, dim3(g_shade), st, d, c->ps, q, nq, n_paths, b, spp_pass, pp.s_lo, q_next, n_next,
-                           c->shadow_queue, &ctr->n_shadow, ctr, trace_all, uni_nx, uni_ny);
+                           c->shadow_queue, &ctr->n_shadow, ctr, trace_all, uni_nx, uni_ny, (const uint32_t*)c->pix_list, pp.px0, prm.seed);
         if (tm) { int e = tm->end(); if (e) return e; }
 
         if (mixed && b + 1 < d.max_depth) {
@@ -1039,14 +1042,14 @@ int check_render_args(cray_ctx* c, cray_scene* s, const cray_render_params* p) {
         set_last_error("cray_render: the traversal counters are defined by the reference's f64 traversal; not available in the f32 fast mode");
         return CRAY_ERR_INVALID;
     }
-    if (p->integrator > CRAY_INTEGRATOR_SIMPLE || p->sampler > CRAY_SAMPLER_UNIFORM) { set_last_error("cray_render: unknown integrator / sampler"); return CRAY_ERR_INVALID; }
+    if (p->integrator > CRAY_INTEGRATOR_SIMPLE || p->sampler > CRAY_SAMPLER_INDEPENDENT) { set_last_error("cray_render: unknown integrator / sampler"); return CRAY_ERR_INVALID; }
     if (p->sampler == CRAY_SAMPLER_UNIFORM) {
         // UniformSampler::num_samples() = nx * ny is what `render` divides by (craytracer.rs:235, 255): it must be the scene's
         if (p->uniform_nx == 0 || p->uniform_ny == 0 || (uint64_t)p->uniform_nx * p->uniform_ny != s->dev.num_samples) {
             set_last_error("cray_render: UniformSampler %u x %u does not give the scene's %u samples", p->uniform_nx, p->uniform_ny, s->dev.num_samples);
             return CRAY_ERR_INVALID;
         }
-    } else if (s->dev.num_samples > 65536) { set_last_error("sobol_burley indexes at most 2^16 samples"); return CRAY_ERR_UNSUPPORTED; }
+    } else if (p->sampler == CRAY_SAMPLER_SOBOL && s->dev.num_samples > 65536) { set_last_error("sobol_burley indexes at most 2^16 samples"); return CRAY_ERR_UNSUPPORTED; }
     if (p->integrator == CRAY_INTEGRATOR_SIMPLE && p->sampler == CRAY_SAMPLER_SOBOL && 4 + 7 * (uint64_t)s->dev.max_depth > 256) {
         set_last_error("max_depth %u needs more than sobol_burley's 256 dimensions", s->dev.max_depth);
         return CRAY_ERR_UNSUPPORTED;

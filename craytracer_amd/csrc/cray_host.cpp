@@ -571,6 +571,15 @@ extern "C" void cray_host_sincos(double x, double* s, double* c) {
     if (c) *c = cv;
 }
 
+extern "C" void cray_host_chacha_block(const uint32_t* key /* [8] */, const uint32_t* w12_15 /* [4] */, int double_rounds, uint32_t* out /* [16] */) {
+    cray::chacha_block(key, w12_15[0], w12_15[1], w12_15[2], w12_15[3], double_rounds, out);
+}
+extern "C" void cray_host_independent_draws(uint64_t seed, uint64_t x, uint64_t y, uint64_t sample_index, uint32_t first, double* out /* [8] */) {
+    uint32_t key[8];
+    cray::indep_key(cray::indep_pixel_hash(seed, x, y, sample_index), key);
+    cray::indep_draws(key, first, out);
+}
+
 extern "C" uint64_t cray_host_sincos_fast_check(const double* x, uint64_t n, double* stats /* [3] */) {
     using namespace cray;
     uint64_t bad = 0, slow = 0;

@@ -682,7 +682,8 @@ __global__ void __launch_bounds__(kBlock) k_make_slots32(const LeafSlot* __restr
 // measured: k_film gets trivially coalesced, but the traversal and k_shade lose the coherence of the 16
 // samples of one pixel sitting in adjacent lanes: +13 ms closest, +8 ms shade per frame.)
 __global__ void __launch_bounds__(kBlock) k_raygen(DevScene sc, PathState ps, const uint32_t* __restrict__ pix_list, uint32_t px0,
-                                                   uint32_t n_paths, uint32_t spp_pass, uint32_t s_lo, uint64_t seed, uint32_t uni_nx, uint32_t uni_ny) {
+                                                   uint32_t n_paths, uint32_t spp_pass, uint32_t s_lo, uint64_t seed, uint32_t uni_nx, uint32_t uni_ny,
+                                                   uint32_t independent) {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n_paths; p += stride) {
         const uint32_t pix = pix_list[px0 + p / spp_pass];
@@ -690,7 +691,12 @@ __global__ void __launch_bounds__(kBlock) k_raygen(DevScene sc, PathState ps, co
         const uint32_t x = pix % sc.film_w, y = pix / sc.film_w;
         const uint32_t h = pixel_seed(seed, x, y);  // SobolSampler::start_pixel
         double u[4];
-        if (uni_nx) {  // UniformSampler::sample_2d (sampling.rs:185-192): the centre of slot (s % nx, s / nx), for film and lens alike
+        if (independent) {  // IndependentSampler (sampling.rs:102-146): the first four draws of the pixel sample's own generator
+            uint32_t key[8], w[16];
+            indep_key(indep_pixel_hash(seed, x, y, s), key);
+            chacha_block(key, 0u, 0u, 0u, 0u, 6, w);
+            for (int j = 0; j < 4; j++) u[j] = indep_unit(w[2 * j], w[2 * j + 1]);
+        } else if (uni_nx) {  // UniformSampler::sample_2d (sampling.rs:185-192): the centre of slot (s % nx, s / nx), for film and lens alike
             u[0] = u[2] = ((double)(s % uni_nx) + 0.5) / (double)uni_nx;
             u[1] = u[3] = ((double)(s / uni_nx) + 0.5) / (double)uni_ny;
         } else {
@@ -730,15 +736,15 @@ __device__ __forceinline__ void queue_push(uint32_t* __restrict__ q, unsigned in
 //      bit 1: UniformSampler (src/sampling.rs:154-194) instead of SobolSampler; uni_nx / uni_ny are its two slot counts.
 // The reference's `main` runs mode 0 (path integrator + Sobol, craytracer.rs:159-160, 361); the others are its selectable
 // alternatives and run on the all-features instantiation only.
-enum { kModeSimple = 1, kModeUniform = 2, kModeLdsTables = 4 };
+enum { kModeSimple = 1, kModeUniform = 2, kModeLdsTables = 4, kModeIndependent = 8 };
 template <uint32_t F, int MODE = 0>
 __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
                                                   const unsigned int* __restrict__ n_ptr, uint32_t n_fixed, uint32_t bounce,
                                                   uint32_t spp_pass, uint32_t s_lo, uint32_t* __restrict__ next_queue,
                                                   unsigned int* next_count, uint32_t* __restrict__ shadow_queue,
                                                   unsigned int* shadow_count, Counters* ctr, uint32_t trace_all_shadow,
-                                                  uint32_t uni_nx, uint32_t uni_ny) {
-    constexpr bool kSimple = (MODE & kModeSimple) != 0, kUniform = (MODE & kModeUniform) != 0;
+                                                  uint32_t uni_nx, uint32_t uni_ny, const uint32_t* __restrict__ pix_list, uint32_t px0, uint64_t seed) {
+    constexpr bool kSimple = (MODE & kModeSimple) != 0, kUniform = (MODE & kModeUniform) != 0, kIndependent = (MODE & kModeIndependent) != 0;
     const uint32_t n = n_ptr ? *n_ptr : n_fixed;
     // Queue appends are aggregated per block over a tile of kShadeTile paths: survivors are collected
     // in LDS (wave ballot + one LDS atomic per wave) and flushed with ONE global atomic per queue and
@@ -842,7 +848,15 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
                 const uint32_t sidx = s_lo + p % spp_pass;
                 const uint32_t h = ps.hash[p];
                 double sa[4], sb[4];
-                if (kUniform) {  // every 1-D draw is (s + 0.5) / (nx ny), every 2-D draw the slot centre (sampling.rs:180-192)
+                if (kIndependent) {  // IndependentSampler: draws 4 + 8 b .. (4 + 7 b .. for simple_integrator) of the pixel sample's generator
+                    const uint32_t pix = pix_list[px0 + p / spp_pass];
+                    uint32_t key[8];
+                    indep_key(indep_pixel_hash(seed, pix % sc.film_w, pix / sc.film_w, sidx), key);
+                    double dr[8];
+                    indep_draws(key, 4u + (kSimple ? 7u : 8u) * bounce, dr);
+                    sa[0] = dr[0]; sa[1] = dr[1]; sa[2] = dr[2]; sa[3] = dr[3];
+                    sb[0] = dr[4]; sb[1] = dr[5]; sb[2] = dr[6]; sb[3] = kSimple ? 0.0 : dr[7];
+                } else if (kUniform) {  // every 1-D draw is (s + 0.5) / (nx ny), every 2-D draw the slot centre (sampling.rs:180-192)
                     const double u1 = ((double)sidx + 0.5) / (double)(uni_nx * uni_ny);
                     const double ux = ((double)(sidx % uni_nx) + 0.5) / (double)uni_nx, uy = ((double)(sidx / uni_nx) + 0.5) / (double)uni_ny;
                     sa[0] = u1; sa[1] = ux; sa[2] = uy; sa[3] = u1;

@@ -588,3 +588,91 @@ CRAY_HD void sincos_cr_dd(double x, double& s_out, double& c_out) {
     c_out = q == 0 ? cv : (q == 1 ? -sv : (q == 2 ? -cv : sv));
 }
 }  // namespace cray
+
+namespace cray {
+CRAY_HD uint64_t rotl64_hd(uint64_t x, int b) { return (x << b) | (x >> (64 - b)); }
+#define CRAY_SIPROUND_HD(v0, v1, v2, v3)                                              \
+    do {                                                                              \
+        v0 += v1; v1 = rotl64_hd(v1, 13); v1 ^= v0; v0 = rotl64_hd(v0, 32);           \
+        v2 += v3; v3 = rotl64_hd(v3, 16); v3 ^= v2;                                   \
+        v0 += v3; v3 = rotl64_hd(v3, 21); v3 ^= v0;                                   \
+        v2 += v1; v1 = rotl64_hd(v1, 17); v1 ^= v2; v2 = rotl64_hd(v2, 32);           \
+    } while (0)
+// =============================================================================
+// IndependentSampler (src/sampling.rs:102-146): start_pixel hashes (seed, x, y, sample_index) with DefaultHasher and reseeds a
+// StdRng from the 64-bit hash; every draw is rng.sample(Uniform::new(0.0, 1.0)).  The crates behind it are NOT in the container
+// (rand 0.8.5, rand_chacha 0.3.1, rand_core 0.6.4), so this restates their PUBLISHED algorithms — PARITY UNPINNED against the crates
+// themselves:
+//   * DefaultHasher = SipHash-1-3 with zero keys over the four usize values as little-endian u64 (pinned like pixel_seed);
+//   * SeedableRng::seed_from_u64: eight steps of a PCG32 (multiplier 6364136223846793005, increment 11634580027462260723, output
+//     XSH-RR) fill the 32-byte seed, little-endian;
+//   * StdRng = ChaCha12: state = "expand 32-byte k", the key, a 64-bit block counter from 0, a 64-bit stream id 0 (djb layout);
+//     12 rounds; blocks are consumed word by word in order (the block function is pinned with rounds = 20 by RFC 8439 2.3.2);
+//   * next_u64 = word[i] | word[i + 1] << 32;  Uniform<f64>::sample = (u64 >> 12 | exponent of 1.0) as f64 - 1.0 (scale 1, low 0).
+// A pixel sample draws film 2-D, lens 2-D (words 0..7), then 8 draws per path segment (7 for simple_integrator), in order.
+// =============================================================================
+CRAY_HD uint64_t indep_pixel_hash(uint64_t seed, uint64_t x, uint64_t y, uint64_t sample_index) {
+    uint64_t v0 = 0x736f6d6570736575ULL, v1 = 0x646f72616e646f6dULL;
+    uint64_t v2 = 0x6c7967656e657261ULL, v3 = 0x7465646279746573ULL;
+    uint64_t m[4] = {seed, x, y, sample_index};
+    for (int i = 0; i < 4; i++) {
+        v3 ^= m[i];
+        CRAY_SIPROUND_HD(v0, v1, v2, v3);
+        v0 ^= m[i];
+    }
+    const uint64_t b = 32ULL << 56;   // 32 bytes hashed, no tail bytes
+    v3 ^= b;
+    CRAY_SIPROUND_HD(v0, v1, v2, v3);
+    v0 ^= b;
+    v2 ^= 0xff;
+    CRAY_SIPROUND_HD(v0, v1, v2, v3);
+    CRAY_SIPROUND_HD(v0, v1, v2, v3);
+    CRAY_SIPROUND_HD(v0, v1, v2, v3);
+    return v0 ^ v1 ^ v2 ^ v3;
+}
+CRAY_HD uint32_t rotl32(uint32_t x, int b) { return (x << b) | (x >> (32 - b)); }
+CRAY_HD void indep_key(uint64_t state, uint32_t key[8]) {   // rand_core seed_from_u64
+    for (int i = 0; i < 8; i++) {
+        state = state * 6364136223846793005ULL + 11634580027462260723ULL;
+        const uint32_t xorshifted = (uint32_t)(((state >> 18) ^ state) >> 27);
+        const uint32_t rot = (uint32_t)(state >> 59);
+        key[i] = (xorshifted >> rot) | (xorshifted << ((32u - rot) & 31u));
+    }
+}
+#define CRAY_CHACHA_QR(a, b, c, d)                         \
+    do {                                                   \
+        a += b; d ^= a; d = rotl32(d, 16);                 \
+        c += d; b ^= c; b = rotl32(b, 12);                 \
+        a += b; d ^= a; d = rotl32(d, 8);                  \
+        c += d; b ^= c; b = rotl32(b, 7);                  \
+    } while (0)
+// one ChaCha block: words 12..15 of the state are passed explicitly (64-bit counter + 64-bit stream id for the generator; counter +
+// nonce for the RFC's test vector)
+CRAY_HD void chacha_block(const uint32_t key[8], uint32_t w12, uint32_t w13, uint32_t w14, uint32_t w15, int double_rounds,
+                                    uint32_t out[16]) {
+    uint32_t x0 = 0x61707865u, x1 = 0x3320646eu, x2 = 0x79622d32u, x3 = 0x6b206574u;
+    uint32_t x4 = key[0], x5 = key[1], x6 = key[2], x7 = key[3], x8 = key[4], x9 = key[5], x10 = key[6], x11 = key[7];
+    uint32_t x12 = w12, x13 = w13, x14 = w14, x15 = w15;
+    for (int r = 0; r < double_rounds; r++) {
+        CRAY_CHACHA_QR(x0, x4, x8, x12); CRAY_CHACHA_QR(x1, x5, x9, x13); CRAY_CHACHA_QR(x2, x6, x10, x14); CRAY_CHACHA_QR(x3, x7, x11, x15);
+        CRAY_CHACHA_QR(x0, x5, x10, x15); CRAY_CHACHA_QR(x1, x6, x11, x12); CRAY_CHACHA_QR(x2, x7, x8, x13); CRAY_CHACHA_QR(x3, x4, x9, x14);
+    }
+    out[0] = x0 + 0x61707865u; out[1] = x1 + 0x3320646eu; out[2] = x2 + 0x79622d32u; out[3] = x3 + 0x6b206574u;
+    out[4] = x4 + key[0]; out[5] = x5 + key[1]; out[6] = x6 + key[2]; out[7] = x7 + key[3];
+    out[8] = x8 + key[4]; out[9] = x9 + key[5]; out[10] = x10 + key[6]; out[11] = x11 + key[7];
+    out[12] = x12 + w12; out[13] = x13 + w13; out[14] = x14 + w14; out[15] = x15 + w15;
+}
+CRAY_HD double indep_unit(uint32_t lo, uint32_t hi) {   // Uniform::new(0.0, 1.0) on one next_u64
+    const uint64_t v = (((uint64_t)hi << 32) | lo) >> 12;
+    return __builtin_bit_cast(double, 0x3ff0000000000000ULL | v) - 1.0;
+}
+// draws first .. first + 7 of the pixel sample whose generator key is `key` (draw j = words 2j, 2j + 1 of the stream)
+CRAY_HD void indep_draws(const uint32_t key[8], uint32_t first, double out[8]) {
+    const uint32_t word0 = 2u * first, blk = word0 >> 4, off = word0 & 15u;
+    uint32_t w[32];
+    chacha_block(key, blk, 0u, 0u, 0u, 6, w);
+    chacha_block(key, blk + 1u, 0u, 0u, 0u, 6, w + 16);
+    for (int j = 0; j < 8; j++) out[j] = indep_unit(w[off + 2 * j], w[off + 2 * j + 1]);
+}
+
+}  // namespace cray

@@ -64,6 +64,8 @@ __device__ __forceinline__ uint32_t pixel_seed(uint64_t seed, uint64_t x, uint64
     return (uint32_t)(v0 ^ v1 ^ v2 ^ v3);
 }
 
+// (IndependentSampler's generator — SipHash of the pixel sample, PCG32 seed expansion, ChaCha12 — lives in cray_math.h: host + device)
+
 __device__ __forceinline__ uint32_t lk_seed_hash(uint32_t n, uint32_t k) {
     uint32_t h = n ^ k;
     h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;

@@ -116,7 +116,7 @@ typedef struct {
      * and UniformSampler (src/sampling.rs:154-194: slot centres, uniform_nx * uniform_ny must equal Scene.num_samples) are
      * what a maintainer gets by editing those lines.  IndependentSampler (rand's ChaCha12 StdRng) is not provided. */
     uint32_t integrator;        /* CRAY_INTEGRATOR_PATH (default) | CRAY_INTEGRATOR_SIMPLE */
-    uint32_t sampler;           /* CRAY_SAMPLER_SOBOL (default) | CRAY_SAMPLER_UNIFORM */
+    uint32_t sampler;           /* CRAY_SAMPLER_SOBOL (default) | CRAY_SAMPLER_UNIFORM | CRAY_SAMPLER_INDEPENDENT */
     uint32_t uniform_nx, uniform_ny;
     /* CRAY_PRECISION_F64 (default): the reference's arithmetic, results identical to it.
      * CRAY_PRECISION_F32_TRAVERSAL: the "fast" mode of SURVEY.md §8(b) — the same tree traversed with f32 node / triangle
@@ -126,7 +126,9 @@ typedef struct {
 } cray_render_params;
 enum { CRAY_PRECISION_F64 = 0, CRAY_PRECISION_F32_TRAVERSAL = 1 };
 enum { CRAY_INTEGRATOR_PATH = 0, CRAY_INTEGRATOR_SIMPLE = 1 };
-enum { CRAY_SAMPLER_SOBOL = 0, CRAY_SAMPLER_UNIFORM = 1 };
+enum { CRAY_SAMPLER_SOBOL = 0, CRAY_SAMPLER_UNIFORM = 1,
+       CRAY_SAMPLER_INDEPENDENT = 2 /* sampling.rs:102-146: per pixel sample a ChaCha12 StdRng seeded from the SipHash of (seed, x, y,
+                                       sample); restated from the published algorithms of rand 0.8.5 — not pinned against the crate */ };
 
 typedef struct {
     uint64_t paths;                         /* W*H*spp rendered by this call */

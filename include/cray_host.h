@@ -47,6 +47,12 @@ void cray_host_scene_free(cray_host_scene* scene);
  * (src/sampling.rs:17-39), evaluated on the host by the very same code (cray_math.h). */
 void cray_host_sincos(double x, double* sin_out, double* cos_out);
 
+/* IndependentSampler's generator as the kernels run it (cray_math.h): one ChaCha block with words 12..15 of the state given
+ * explicitly (double_rounds = 6 is ChaCha12, 10 is the RFC 8439 ChaCha20 whose section 2.3.2 vector pins the block function),
+ * and draws first .. first + 7 of pixel sample (seed, x, y, sample_index). */
+void cray_host_chacha_block(const uint32_t* key, const uint32_t* w12_15, int double_rounds, uint32_t* out);
+void cray_host_independent_draws(uint64_t seed, uint64_t x, uint64_t y, uint64_t sample_index, uint32_t first, double* out);
+
 /* The short evaluation + rounding test of the sampling sin/cos (cray_math.h sincos_fast_core) against the double-double evaluation
  * it falls back to: returns the number of arguments on which sincos_cr differs from the double-double result in any bit (must be 0);
  * stats[0] = calls that took the fallback, stats[1] = largest deviation of the short evaluation's candidate from the double-double

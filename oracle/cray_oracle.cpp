@@ -17,6 +17,9 @@
  *    sampler below restates Burley's Owen-scrambled Sobol from the published
  *    algorithm with scipy's Joe-Kuo direction numbers.  End-to-end images are
  *    therefore "oracle == product", conditional on that table for "== real binary".
+ *  - UNPINNED: IndependentSampler's generator (rand 0.8.5, rand_chacha 0.3.1, rand_core 0.6.4: Cargo.lock, not in
+ *    /root/reference) is restated from the crates' published algorithms (StdRngRestated below); `main` never selects that
+ *    sampler.  Pinned only as far as RFC 8439's ChaCha vector and agreement of two implementations go (tests/test_alternatives.py).
  *  - The reference binary itself cannot be built here (no rustc/cargo).
  */
 #include <quadmath.h>
@@ -168,19 +171,81 @@ static inline float sobol_sample(uint32_t sample_index, uint32_t dimension, uint
  * integrator (craytracer.rs:159-160, 361); UniformSampler (sampling.rs:154-194) and simple_integrator::estimate_Li
  * (simple_integrator.rs:36-143) are its selectable alternatives. */
 static int g_integrator = 0;                 /* 0 path_integrator, 1 simple_integrator */
-static int g_sampler_kind = 0;               /* 0 Sobol, 1 Uniform */
+static int g_sampler_kind = 0;               /* 0 Sobol, 1 Uniform, 2 Independent */
 static uint64_t g_uniform_nx = 1, g_uniform_ny = 1;
 
-/* SobolSampler, src/sampling.rs:196-247; UniformSampler, :154-194 */
+/* IndependentSampler's generator (sampling.rs:102-146): `StdRng::seed_from_u64(hash)` and `rng.sample(Uniform::new(0.0, 1.0))`.
+ * rand 0.8.5 / rand_chacha 0.3.1 / rand_core 0.6.4 are NOT in the container: this restates their published algorithms (PCG32
+ * XSH-RR seed expansion, ChaCha with 12 rounds, 64-bit block counter and stream id 0, words consumed in order, 52 random mantissa
+ * bits) — PARITY UNPINNED against the crates.  Written as a byte-oriented stream generator, independently of the kernels' version. */
+struct StdRngRestated {
+    uint8_t seed[32];
+    uint64_t block;      /* next block counter */
+    uint8_t buf[64];     /* current block, little-endian words */
+    int used;            /* bytes of buf consumed */
+    static uint32_t rotl(uint32_t v, int n) { return (v << n) | (v >> (32 - n)); }
+    void seed_from_u64(uint64_t state) {
+        for (int i = 0; i < 8; i++) {
+            state = state * 6364136223846793005ULL + 11634580027462260723ULL;
+            uint32_t xs = (uint32_t)(((state >> 18) ^ state) >> 27), rot = (uint32_t)(state >> 59);
+            uint32_t v = rot ? ((xs >> rot) | (xs << (32 - rot))) : xs;
+            for (int b = 0; b < 4; b++) seed[4 * i + b] = (uint8_t)(v >> (8 * b));
+        }
+        block = 0; used = 64;
+    }
+    void refill() {
+        uint32_t st[16], x[16];
+        static const char sigma[17] = "expand 32-byte k";
+        for (int i = 0; i < 4; i++) st[i] = (uint32_t)(uint8_t)sigma[4 * i] | (uint32_t)(uint8_t)sigma[4 * i + 1] << 8 | (uint32_t)(uint8_t)sigma[4 * i + 2] << 16 | (uint32_t)(uint8_t)sigma[4 * i + 3] << 24;
+        for (int i = 0; i < 8; i++) st[4 + i] = (uint32_t)seed[4 * i] | (uint32_t)seed[4 * i + 1] << 8 | (uint32_t)seed[4 * i + 2] << 16 | (uint32_t)seed[4 * i + 3] << 24;
+        st[12] = (uint32_t)block; st[13] = (uint32_t)(block >> 32); st[14] = 0; st[15] = 0;
+        memcpy(x, st, sizeof(x));
+        static const int idx[8][4] = {{0, 4, 8, 12}, {1, 5, 9, 13}, {2, 6, 10, 14}, {3, 7, 11, 15}, {0, 5, 10, 15}, {1, 6, 11, 12}, {2, 7, 8, 13}, {3, 4, 9, 14}};
+        for (int round = 0; round < 12; round += 2)
+            for (int q = 0; q < 8; q++) {
+                uint32_t &a = x[idx[q][0]], &b = x[idx[q][1]], &c = x[idx[q][2]], &d = x[idx[q][3]];
+                a += b; d = rotl(d ^ a, 16);
+                c += d; b = rotl(b ^ c, 12);
+                a += b; d = rotl(d ^ a, 8);
+                c += d; b = rotl(b ^ c, 7);
+            }
+        for (int i = 0; i < 16; i++) {
+            uint32_t v = x[i] + st[i];
+            for (int b = 0; b < 4; b++) buf[4 * i + b] = (uint8_t)(v >> (8 * b));
+        }
+        block += 1; used = 0;
+    }
+    uint64_t next_u64() {   /* two consecutive u32 words, low word first (BlockRng::next_u64) */
+        if (used == 64) refill();
+        uint64_t v = 0;
+        for (int b = 0; b < 8; b++) v |= (uint64_t)buf[used + b] << (8 * b);
+        used += 8;
+        return v;
+    }
+    double uniform01() {    /* UniformFloat<f64>::sample with low = 0, scale = 1 */
+        uint64_t bits = (next_u64() >> 12) | 0x3ff0000000000000ULL;
+        double v;
+        memcpy(&v, &bits, 8);
+        return v - 1.0;
+    }
+};
+
+/* SobolSampler, src/sampling.rs:196-247; UniformSampler, :154-194; IndependentSampler, :102-146 */
 struct Sampler {
     uint64_t seed;
     uint32_t hash, sample_index, dimension;
+    StdRngRestated rng;
     void start_pixel(uint64_t x, uint64_t y, uint64_t s) {
         hash = pixel_hash(seed, x, y);
         sample_index = (uint32_t)s;
         dimension = 0;
+        if (g_sampler_kind == 2) { /* :125-137 */
+            uint64_t w[4] = {seed, x, y, s};
+            rng.seed_from_u64(siphash13(w, 4, 0, 0));
+        }
     }
     double sample_1d() { /* :234-238 */
+        if (g_sampler_kind == 2) return rng.uniform01(); /* :139-141 */
         if (g_sampler_kind == 1) /* :180-183 */
             return ((double)sample_index + 0.5) / (double)(g_uniform_nx * g_uniform_ny);
         float s = sobol_sample(sample_index, dimension, hash);
@@ -188,6 +253,7 @@ struct Sampler {
         return (double)s;
     }
     void sample_2d(double* a, double* b) { /* :240-246 */
+        if (g_sampler_kind == 2) { *a = rng.uniform01(); *b = rng.uniform01(); return; } /* :143-145 */
         if (g_sampler_kind == 1) { /* :185-192 */
             uint64_t x = sample_index % g_uniform_nx, y = sample_index / g_uniform_nx;
             *a = ((double)x + 0.5) / (double)g_uniform_nx;
@@ -1595,7 +1661,15 @@ void orc_camera_ray(void* s, uint64_t seed, uint32_t x, uint32_t y, uint32_t sam
 
 /* 0: correctly rounded sin/cos in the sampling functions (default); 1: platform libm */
 void orc_set_libm_mode(int mode) { g_libm_mode = mode; }
-/* integrator: 0 path, 1 simple; sampler: 0 Sobol, 1 Uniform(nx, ny) */
+/* the first n draws of IndependentSampler for pixel sample (seed, x, y, sample_index) */
+void orc_independent_draws(uint64_t seed, uint64_t x, uint64_t y, uint64_t sample_index, int n, double* out) {
+    StdRngRestated r;
+    uint64_t w[4] = {seed, x, y, sample_index};
+    r.seed_from_u64(siphash13(w, 4, 0, 0));
+    for (int i = 0; i < n; i++) out[i] = r.uniform01();
+}
+
+/* integrator: 0 path, 1 simple; sampler: 0 Sobol, 1 Uniform(nx, ny), 2 Independent */
 void orc_set_mode(int integrator, int sampler, uint64_t nx, uint64_t ny) {
     g_integrator = integrator; g_sampler_kind = sampler;
     g_uniform_nx = nx ? nx : 1; g_uniform_ny = ny ? ny : 1;

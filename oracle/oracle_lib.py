@@ -105,11 +105,13 @@ def set_libm_mode(mode):
     lib().orc_set_libm_mode(mode)
 
 
-def set_mode(integrator='path', uniform_sampler=None):
+def set_mode(integrator='path', uniform_sampler=None, independent_sampler=False):
     """Which of the reference's integrators / samplers the oracle runs: 'path' (main's) or 'simple'
-    (src/simple_integrator.rs); uniform_sampler = (nx, ny) selects UniformSampler (sampling.rs:154-194), None the Sobol sampler."""
+    (src/simple_integrator.rs); uniform_sampler = (nx, ny) selects UniformSampler (sampling.rs:154-194), independent_sampler
+    IndependentSampler (:102-146, restated from rand 0.8.5's published algorithms: unpinned), neither the Sobol sampler."""
     nx, ny = uniform_sampler if uniform_sampler is not None else (0, 0)
-    lib().orc_set_mode({'path': 0, 'simple': 1}[integrator], 1 if uniform_sampler is not None else 0, nx, ny)
+    kind = 1 if uniform_sampler is not None else (2 if independent_sampler else 0)
+    lib().orc_set_mode({'path': 0, 'simple': 1}[integrator], kind, nx, ny)
 
 
 def set_sobol_vectors(table):

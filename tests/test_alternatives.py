@@ -1,5 +1,7 @@
 """The reference's selectable alternatives: simple_integrator::estimate_Li
-(src/simple_integrator.rs:36-143) and UniformSampler (src/sampling.rs:154-194).  `main` hard-wires the path integrator and
+(src/simple_integrator.rs:36-143), UniformSampler (src/sampling.rs:154-194) and IndependentSampler (:102-146; its generator
+is restated from rand 0.8.5's published algorithms, the crate is not in the container: pinned here by RFC 8439's ChaCha vector
+and by two independent implementations agreeing, NOT against the crate).  `main` hard-wires the path integrator and
 the Sobol sampler (craytracer.rs:159-160, 361); these are what a maintainer gets by editing those two lines, so oracle and
 product offer them as options of `render` (cray_render_params.integrator / .sampler).  CPU: the oracle's restatement behaves
 like the source says; GPU: the HIP path equals the oracle bit for bit in all four combinations."""
@@ -15,6 +17,45 @@ from tests.parity_util import small_scenes
 def _restore_mode():
     yield
     ol.set_mode('path', None)
+
+
+def test_chacha_block_function_against_rfc_8439():
+    """The kernels' ChaCha block function with 10 double rounds, the RFC's key / counter / nonce (section 2.3.2): the sixteen
+    output words of the RFC.  StdRng is the same function with 6 double rounds, a 64-bit counter and stream id 0."""
+    L = backend.lib()
+    key = np.frombuffer(bytes(range(32)), dtype='<u4').copy()
+    w = np.array([1, 0x09000000, 0x4a000000, 0], dtype=np.uint32)
+    out = np.zeros(16, dtype=np.uint32)
+    L.cray_host_chacha_block(key.ctypes.data, w.ctypes.data, 10, out.ctypes.data)
+    want = ('e4e7f110 15593bd1 1fdd0f50 c47120a3 c7f4d1c7 0368c033 9aaa2204 4e6cd4c3 '
+            '466482d2 09aa9f07 05d7c214 a2028bd9 d19c12b5 b94e16de e883d0cb 4e3c50a2')
+    assert ' '.join('%08x' % x for x in out) == want
+
+
+def test_independent_sampler_two_implementations_one_stream():
+    """The oracle's byte-stream restatement of StdRng (seed_from_u64, ChaCha12 blocks in order, next_u64, Uniform<f64>) and the
+    kernels' windowed one (draws first .. first + 7 from two blocks) give the same doubles for every window, across block
+    boundaries; draws lie in [0, 1) with 52 random bits, different pixel samples get different streams."""
+    import ctypes as C
+    H, O = backend.lib(), ol.lib()
+    O.orc_independent_draws.argtypes = [C.c_uint64] * 4 + [C.c_int, C.c_void_p]
+    rng = np.random.default_rng(5)
+    seen = set()
+    for _ in range(300):
+        seed, x, y, s = (int(v) for v in rng.integers(0, 1 << 40, 4))
+        ref = np.zeros(128)
+        O.orc_independent_draws(seed, x, y, s, 128, ref.ctypes.data)
+        assert ref.min() >= 0.0 and ref.max() < 1.0
+        assert np.all(ref * 2.0 ** 52 == np.floor(ref * 2.0 ** 52))      # multiples of 2^-52
+        for first in (0, 4, 11, 12, 60, 4 + 8 * 9, 4 + 7 * 11, 120):
+            d = np.zeros(8)
+            H.cray_host_independent_draws(seed, x, y, s, first, d.ctypes.data)
+            assert np.array_equal(d, ref[first:first + 8]), first
+        seen.add(ref[:4].tobytes())
+    assert len(seen) == 300
+    many = np.zeros(100000)
+    O.orc_independent_draws(1, 2, 3, 4, 100000, many.ctypes.data)
+    assert abs(many.mean() - 0.5) < 0.005 and abs(many.var() - 1 / 12) < 0.002
 
 
 def test_uniform_sampler_draws_slot_centres():
@@ -48,7 +89,7 @@ def test_simple_integrator_agrees_with_the_path_integrator_in_the_mean():
     assert bst['paths'] == ast['paths'] and bst['nonfinite'] == 0
 
 
-MODES = [('simple', None), ('path', 'uniform'), ('simple', 'uniform')]
+MODES = [('simple', None), ('path', 'uniform'), ('simple', 'uniform'), ('path', 'independent'), ('simple', 'independent')]
 
 
 @pytest.mark.gpu
@@ -59,8 +100,8 @@ def test_alternatives_are_pixel_exact_on_the_gpu(name, integrator, sampler):
     uni = (4, 2) if sampler == 'uniform' else None
     ctx = backend.Context(0)
     dev = ctx.upload(backend.HostScene(sc))
-    dev.integrator, dev.uniform_sampler = integrator, uni
-    ol.set_mode(integrator, uni)
+    dev.integrator, dev.uniform_sampler, dev.independent_sampler = integrator, uni, sampler == 'independent'
+    ol.set_mode(integrator, uni, sampler == 'independent')
     orc = ol.OracleScene(sc)
     g, gst = dev.render(seed=2, count_traversal=True)
     o, ost = orc.render(seed=2)
