@@ -158,7 +158,7 @@ def test_sincos_short_evaluation_never_differs_from_the_double_double_one():
         st = np.zeros(3)
         bad = L.cray_host_sincos_fast_check(xs.ctypes.data, len(xs), st.ctypes.data)
         assert bad == 0
-        assert st[1] < 0.34, st        # observed: 0.26 of the radius on 2.4 x 10^8 arguments
+        assert st[1] < 0.34, st        # observed: 0.26 of the radius on 10^9 arguments
         assert st[0] < 0.01 * len(xs), st
 
 
