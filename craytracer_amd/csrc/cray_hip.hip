@@ -1543,9 +1543,13 @@ Rccl* rccl() {
     if (api.handle) return &api;
     if (tried) return nullptr;
     tried = true;
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    // CRAY_RCCL_LIB=<path>: a particular build of the collective library (the tests use it to put several ranks on one GPU
+    // through a shared-memory stand-in, tests/mock_rccl/)
+    const char* forced = getenv("CRAY_RCCL_LIB");
+    for (const char* name : {forced, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        if (!name || !name[0]) continue;
         api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-        if (api.handle) break;
+        if (api.handle || name == forced) break;   // a forced library that does not load is an error, not a fallback
     }
     if (!api.handle) { set_last_error("cannot load librccl.so.1: %s", dlerror()); return nullptr; }
     bool ok = true;

@@ -31,7 +31,9 @@
 
 static int run_rank(int rank, int world, const cray_comm_id* id, const char* out_path) {
     cray_ctx* ctx = NULL;
-    CHECK(cray_ctx_create(rank /* GPU = local rank */, NULL, &ctx));
+    /* GPU = local rank; CRAY_ONE_DEVICE=1 puts every rank on GPU 0 (rehearsals on a one-GPU box with a stand-in collective
+     * library, CRAY_RCCL_LIB: real RCCL refuses two ranks on one device) */
+    CHECK(cray_ctx_create(getenv("CRAY_ONE_DEVICE") ? 0 : rank, NULL, &ctx));
     CHECK(cray_comm_init(ctx, id, rank, world));
 
     /* the host side of the reference (parse, Scene::new) runs once, on rank 0 */

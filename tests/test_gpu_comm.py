@@ -10,6 +10,7 @@ The N > 1 transport itself (grouped ncclSend / ncclRecv) needs N GPUs: bench.py 
 """
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -110,3 +111,49 @@ def test_c_host_multi_gpu_example_with_one_rank(tmp_path):
     r = subprocess.run([exes['multi_gpu'], '1', out2], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert np.array_equal(backend.read_exr(out1), backend.read_exr(out2))
+    # ... and with three ranks on the one GPU, through the shared-memory stand-in for the collective library
+    so = str(tmp_path / 'libmock_rccl.so')
+    subprocess.check_call(['hipcc', '-std=c++17', '-O2', '-fPIC', '-shared', '-o', so,
+                           os.path.join(ROOT, 'tests', 'mock_rccl', 'mock_rccl.cpp'), '-lrt'], stderr=subprocess.DEVNULL)
+    out3 = str(tmp_path / 'c.exr')
+    r = subprocess.run([exes['multi_gpu'], '3', out3], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, CRAY_RCCL_LIB=so, CRAY_ONE_DEVICE='1'))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert np.array_equal(backend.read_exr(out1), backend.read_exr(out3))
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_several_ranks_on_one_gpu_through_the_mock_transport(tmp_path, world):
+    """The N > 1 code path of the C ABI with N processes on the ONE GPU of this box: real RCCL refuses two ranks on a device,
+    so the collective library is replaced (CRAY_RCCL_LIB) by tests/mock_rccl — shared-memory mailboxes behind the ten nccl*
+    entry points the library binds.  Everything but the transport is the product's: communicator set-up, barrier and
+    all-reduce, the scene built on rank 0 and replicated array by array, every rank rendering its tiles, the packed tiles
+    received at their offsets and unpacked on rank 0.  The gathered film must be the unsharded film, bit for bit."""
+    backend.lib()
+    so = str(tmp_path / 'libmock_rccl.so')
+    subprocess.check_call(['hipcc', '-std=c++17', '-O2', '-fPIC', '-shared', '-o', so,
+                           os.path.join(ROOT, 'tests', 'mock_rccl', 'mock_rccl.cpp'), '-lrt'], stderr=subprocess.DEVNULL)
+    env = dict(os.environ, CRAY_RCCL_LIB=so)
+    worker = os.path.join(ROOT, 'tests', 'mock_rccl', 'worker.py')
+    id_path, out_path = str(tmp_path / 'comm.id'), str(tmp_path / 'film.npy')
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), id_path, out_path], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    assert all(p.returncode == 0 for p in procs), '\n'.join(outs)
+    films = np.load(out_path)
+    c = backend.Context(0)
+    dev = c.upload(backend.HostScene(scenes.dragon(200, 136, 8, 6, nu=60, nv=150), resident=True))
+    for k, seed in enumerate((5, 6)):
+        want, _ = dev.render(seed=seed)
+        assert np.array_equal(films[k], want)
+    dev.close()
+    c.close()
+
