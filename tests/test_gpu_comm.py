@@ -157,3 +157,24 @@ def test_several_ranks_on_one_gpu_through_the_mock_transport(tmp_path, world):
     dev.close()
     c.close()
 
+
+def test_bench_with_two_ranks_as_the_driver_launches_it(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` — the driver's command for N = 2 — on the one GPU
+    of this box, the collective library replaced by the shared-memory stand-in: the id exchange over the rendezvous store,
+    communicator, scene broadcast, render + gather and the max-over-ranks timing run as they will on two GPUs, and rank 0
+    prints exactly one JSON line."""
+    import json
+    so = str(tmp_path / 'libmock_rccl.so')
+    subprocess.check_call(['hipcc', '-std=c++17', '-O2', '-fPIC', '-shared', '-o', so,
+                           os.path.join(ROOT, 'tests', 'mock_rccl', 'mock_rccl.cpp'), '-lrt'], stderr=subprocess.DEVNULL)
+    env = dict(os.environ, CRAY_RCCL_LIB=so)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', '29547', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                        '--workload', 'cornell', '--cpu-baseline', '0'], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 2 and d['value'] > 0 and d['scaling'] == 'strong'
+    assert 'cray_render_gather' in d['config']['parallelism']
+
