@@ -245,10 +245,16 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
                 if (!resolve) r3 = rec[3];
                 if (at_leaf) r4 = rec[4];
             }
-        } else if (active) {
-            const double2* rec = at_leaf ? reinterpret_cast<const double2*>(sc.slots + ref_leaf_first(cur))
-                                         : reinterpret_cast<const double2*>(sc.inner + cur);
-            r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3]; r4 = rec[4]; r5 = rec[5]; r6 = rec[6];
+        } else {
+            // the wave that is about to request its records goes first: its loads are what everything after waits for
+            // (s_setprio: -0.4 % on configs[2] and [3], consistently)
+            __builtin_amdgcn_s_setprio(3);
+            if (active) {
+                const double2* rec = at_leaf ? reinterpret_cast<const double2*>(sc.slots + ref_leaf_first(cur))
+                                             : reinterpret_cast<const double2*>(sc.inner + cur);
+                r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3]; r4 = rec[4]; r5 = rec[5]; r6 = rec[6];
+            }
+            __builtin_amdgcn_s_setprio(0);
         }
         if (HYB && active && resolve) {
             // the decision that brought the lane to `cur`, retaken exactly (bounds.rs:46-88 in f64)
