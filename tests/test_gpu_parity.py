@@ -310,3 +310,57 @@ def test_other_cameras(kind):
     assert float(g.mean()) > 1e-3
     dev.close()
     ctx.close()
+
+
+def test_leaves_of_four_primitives_of_mixed_kinds():
+    """Six leaves of four co-centred primitives each — sphere, triangle, ring disk, triangle, in the reference's leaf order —
+    (the SAH cannot split equal centroids): the traversal steps through a leaf one slot per iteration, across shape kinds,
+    with any-hit rays leaving in the middle of a leaf.  Hits, distances and the node / primitive counters of the oracle; film
+    pixel-exact through metal, glass and matte on every kind."""
+    from craytracer_amd import scene as S
+
+    def cluster(c, mats):
+        cx, cy, cz = c
+        return [S.Primitive.new(S.Shape.new_sphere(c, 0.25), mats[0]),
+                S.Primitive.new(S.Shape.new_triangle((cx - 0.375, cy - 0.375, cz + 0.125), (cx + 0.375, cy - 0.375, cz - 0.125), (cx, cy + 0.375, cz)), mats[1]),
+                S.Primitive.new(S.Shape.new_disk(c, 0, 0, 0.375, 0.125), mats[2]),
+                S.Primitive.new(S.Shape.new_triangle((cx - 0.25, cy + 0.25, cz - 0.0625), (cx + 0.25, cy + 0.25, cz + 0.0625), (cx, cy - 0.25, cz)), mats[3])]
+
+    white = S.Material.new_matte(S.Color(1, 1, 1), 0.0)
+    red = S.Material.new_matte(S.Color(1, 0.2, 0.2), 20.0)
+    metal = S.Material.new_metal(S.Color(0.9, 0.8, 0.4), S.Color(4, 3, 2))
+    glass = S.Material.new_glass(S.Color(1, 1, 1), S.Color(0.9, 0.9, 0.9), 1.5)
+    prims = []
+    for i, c in enumerate([(0, 0, 0), (1.5, 0, 0), (0, 1.5, 0), (1.5, 1.5, 0), (0.75, 0.75, 1.0), (3, 0, 0.5)]):
+        m = [white, red, metal, glass]
+        prims += cluster(tuple(float(v) for v in c), m[i % 4:] + m[:i % 4])
+    prims.append(S.Primitive.new(S.Shape.new_sphere((0.75, -100.5, 0), 100.0), white))
+    sl = S.Shape.new_disk((0.75, 3.5, -1.0), 90, 0, 0.75, 0)
+    prims.append(S.Primitive.new_area_light(sl, S.Light.Area(sl, S.Color(8, 8, 8))))
+    cam = S.Camera.perspective(S.Film(64, 48), (0.75, 1.0, -5.0), (0.75, 0.75, 0), (0, 1, 0), 50)
+    sc = S.Scene(6, 8, cam, [S.Light.Point((0.75, 3, -3), S.Color(4, 4, 4))], prims)
+    orc = ol.OracleScene(sc)
+    nodes, _ = orc.bvh()
+    assert int((nodes[nodes['leaf'] != 0]['count'] == 4).sum()) == 6
+    ctx = backend.Context(0)
+    for resident in (False, True):
+        dev = ctx.upload(backend.HostScene(sc, resident=resident))
+        g, gst = dev.render(seed=1, count_traversal=True)
+        o, ost = orc.render(seed=1)
+        assert np.array_equal(g, o.astype(np.float32))
+        for k in ('closest_rays', 'shadow_rays', 'closest_nodes', 'closest_prims', 'shadow_nodes', 'shadow_prims'):
+            assert gst[k] == ost[k], k
+        assert np.array_equal(dev.render(seed=1)[0], g)                 # the timed kernels (mixed launches)
+        rays = random_rays(orc, 6000, seed=8, scale=6.0)
+        rays[::2, 6] = np.random.default_rng(2).uniform(0.5, 8.0, len(rays[::2]))
+        gh, ghs = dev.trace(rays)
+        oh, ohs = orc.trace(rays)
+        assert np.array_equal(gh['hit'], oh['hit']) and np.array_equal(gh['prim'], oh['prim']) and np.array_equal(gh['t'], oh['t'])
+        assert ghs['closest_nodes'] == ohs['closest_nodes'] and ghs['closest_prims'] == ohs['closest_prims']
+        ga, gas = dev.trace(rays, any_hit=True)
+        oa, oas = orc.trace(rays, any_hit=True)
+        assert np.array_equal(ga['hit'], oa['hit'])
+        assert gas['shadow_nodes'] == oas['shadow_nodes'] and gas['shadow_prims'] == oas['shadow_prims']
+        assert int(oh['hit'].sum()) > 500
+        dev.close()
+    ctx.close()
