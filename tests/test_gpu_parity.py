@@ -317,28 +317,8 @@ def test_leaves_of_four_primitives_of_mixed_kinds():
     (the SAH cannot split equal centroids): the traversal steps through a leaf one slot per iteration, across shape kinds,
     with any-hit rays leaving in the middle of a leaf.  Hits, distances and the node / primitive counters of the oracle; film
     pixel-exact through metal, glass and matte on every kind."""
-    from craytracer_amd import scene as S
-
-    def cluster(c, mats):
-        cx, cy, cz = c
-        return [S.Primitive.new(S.Shape.new_sphere(c, 0.25), mats[0]),
-                S.Primitive.new(S.Shape.new_triangle((cx - 0.375, cy - 0.375, cz + 0.125), (cx + 0.375, cy - 0.375, cz - 0.125), (cx, cy + 0.375, cz)), mats[1]),
-                S.Primitive.new(S.Shape.new_disk(c, 0, 0, 0.375, 0.125), mats[2]),
-                S.Primitive.new(S.Shape.new_triangle((cx - 0.25, cy + 0.25, cz - 0.0625), (cx + 0.25, cy + 0.25, cz + 0.0625), (cx, cy - 0.25, cz)), mats[3])]
-
-    white = S.Material.new_matte(S.Color(1, 1, 1), 0.0)
-    red = S.Material.new_matte(S.Color(1, 0.2, 0.2), 20.0)
-    metal = S.Material.new_metal(S.Color(0.9, 0.8, 0.4), S.Color(4, 3, 2))
-    glass = S.Material.new_glass(S.Color(1, 1, 1), S.Color(0.9, 0.9, 0.9), 1.5)
-    prims = []
-    for i, c in enumerate([(0, 0, 0), (1.5, 0, 0), (0, 1.5, 0), (1.5, 1.5, 0), (0.75, 0.75, 1.0), (3, 0, 0.5)]):
-        m = [white, red, metal, glass]
-        prims += cluster(tuple(float(v) for v in c), m[i % 4:] + m[:i % 4])
-    prims.append(S.Primitive.new(S.Shape.new_sphere((0.75, -100.5, 0), 100.0), white))
-    sl = S.Shape.new_disk((0.75, 3.5, -1.0), 90, 0, 0.75, 0)
-    prims.append(S.Primitive.new_area_light(sl, S.Light.Area(sl, S.Color(8, 8, 8))))
-    cam = S.Camera.perspective(S.Film(64, 48), (0.75, 1.0, -5.0), (0.75, 0.75, 0), (0, 1, 0), 50)
-    sc = S.Scene(6, 8, cam, [S.Light.Point((0.75, 3, -3), S.Color(4, 4, 4))], prims)
+    from tests.parity_util import mixed_leaf_scene
+    sc = mixed_leaf_scene()
     orc = ol.OracleScene(sc)
     nodes, _ = orc.bvh()
     assert int((nodes[nodes['leaf'] != 0]['count'] == 4).sum()) == 6

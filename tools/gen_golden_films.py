@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Generates tests/golden/films/<scene>.npz — the CPU oracle's film (f32, seed 0) and query counters — and
-tests/golden/hits/<scene>.npz — 256 rays with the oracle's closest-hit records and any-hit answers — for the five
+tests/golden/hits/<scene>.npz — 256 rays with the oracle's closest-hit records and any-hit answers — for the
 small parity scenes of tests/parity_util.py (self-generated fixtures: they come from the oracle, not from the reference).  The fixtures pin the oracle itself against regressions (CPU suite)
 and give the GPU suite committed expected outputs besides the live oracle.
 
