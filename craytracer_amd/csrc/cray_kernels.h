@@ -908,7 +908,6 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
                 }
 
                 // next-event estimation (:129-164): build the shadow ray and the term it gates
-#ifndef CRAY_EXP_NO_NEE
                 // A material without a diffuse lobe makes the gated term exactly zero: the light is not even
                 // sampled (unless traversal is being counted).  Deviation from the reference only where it
                 // would panic anyway: a non-finite Li / pdf factor times that zero (NaN) on an unoccluded ray.
@@ -980,18 +979,12 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
                         ps.cr[p] = contrib.r; ps.cg[p] = contrib.g; ps.cb[p] = contrib.b;
                     }
                 }
-#endif
 
                 // BSDF sample, throughput update, roulette (:167-206)
                 LobeSample ls;
-#ifdef CRAY_EXP_NO_BSDF
-                ls.w_i = reflect(w_o, n_s); ls.f = mkc(1, 1, 1); ls.pdf = 1.0; ls.delta = true; ls.specular = true;
-                bool go = true;
-#else
                 // an area light's own surface is a black Lambertian (primitive.rs:40-46): its sampled f is BLACK, the
                 // path ends (`if f.is_black() { break }`, path_integrator.rs:176-178) whatever direction was drawn
                 bool go = mat >= 0 && material_sample<F>(sc, mat, sa[0], sa[1], sa[2], w_o, n_s, sp.u, sp.v, ls);
-#endif
                 if (go && black(ls.f)) go = false;
                 double bsdf_pdf = 0.0;
                 if (go) {
