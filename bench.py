@@ -246,6 +246,10 @@ def main():
                     'alg_bytes_per_launch': round(alg_bytes_frame / max(1.0, launches_per_frame)),
                     'avg_launch_ms': round(avg_ms, 4), 'launches_per_step': launches_per_frame,
                     'bytes_per_ray': round(alg_bytes_frame / max(1, traced), 1)}
+        if provenance and ent.get('units'):
+            # what else the same profiled build showed per kernel (separate --pmc passes): lower bound of the share of time the SIMDs
+            # issue VALU work, texture-addresser busy share, share of wave-cycles waiting — the units that do bound this path
+            roofline['other_units'] = {'source': ent.get('units_source'), 'kernels': ent['units']}
         # the second kernel of the frame: k_shade (path state + shading records)
         n_shaded = cst['closest_rays']                      # every traced segment is shaded once
         n_hit = cst.get('closest_hits', 0) or n_shaded      # segments that hit something

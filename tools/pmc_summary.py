@@ -31,6 +31,10 @@ for k, e in res.items():
     if 'TA_TA_BUSY_sum' in e and e.get('GRBM_GUI_ACTIVE'):
         # TA_TA_BUSY_sum adds the 256 TAs, GRBM_GUI_ACTIVE adds the 8 XCDs
         e['ta_busy'] = round((e['TA_TA_BUSY_sum'] / 256.0) / (e['GRBM_GUI_ACTIVE'] / 8.0), 3)
+    if e.get('SQ_INSTS_VALU') and e.get('GRBM_GUI_ACTIVE'):
+        # a wave64 VALU instruction occupies its SIMD for >= 4 cycles (more for the quarter-rate f64 ops): a LOWER bound of the
+        # share of time the 1024 SIMDs spend issuing VALU work
+        e['valu_issue_share_min'] = round(e['SQ_INSTS_VALU'] * 4.0 / (1024.0 * e['GRBM_GUI_ACTIVE'] / 8.0), 3)
 json.dump(res, open(out, 'w'), indent=1, sort_keys=True)
 for k, e in sorted(res.items()):
     print(k, {x: e[x] for x in ('dispatches', 'valu_lane_utilisation', 'wait_any_share_of_wave_cycles', 'salu_per_valu', 'tcc_hit_rate', 'ta_busy', 'SQ_INSTS_VALU') if x in e})

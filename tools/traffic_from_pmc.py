@@ -5,7 +5,9 @@ HBM bytes = FETCH_SIZE[KB] * 1024 * 2: on gfx950 FETCH_SIZE counts 128-B request
 (MI355X_MICROARCH.md "HBM"); tools/calib_fetch.hip confirms the factor for THIS access pattern
 (random whole 128-B records, 16 B per lane per load: 1.707 GB reported for 3.322 GB read; a
 coalesced 16-B/lane stream: 1.611 GB reported for 3.221 GB read).  WRITE_SIZE is taken as is.
-usage: traffic_from_pmc.py <workload> <fetch counter_collection.csv> [<write counter_collection.csv>]"""
+usage: traffic_from_pmc.py <workload> <fetch counter_collection.csv> [<write counter_collection.csv> [<pmc_summary.json>]]
+(the summary of tools/pmc_summary.py adds, per traversal / shading kernel, how busy the other units were: VALU issue, texture
+addresser, share of wave-cycles spent waiting)"""
 import json
 import os
 import sys
@@ -36,6 +38,9 @@ if __name__ == '__main__':
         git += '+dirty' if dirty else ''
     except Exception:
         git = None
+    prev = data.get(workload, {})
+    if prev.get('source') == os.path.relpath(fetch_csv, root) and prev.get('git'):
+        git = prev['git']   # the same counter file processed again: keep the hash of the build that was profiled
     entry = {'source': os.path.relpath(fetch_csv, root), 'git': git, 'fetch_correction': FETCH_CORRECTION, 'kernels': {}}
     for k in fs:
         entry['kernels'][k] = {'launches': int(fc[k]), 'fetch_bytes_per_launch': fs[k] * 1024 * FETCH_CORRECTION / fc[k]}
@@ -54,6 +59,11 @@ if __name__ == '__main__':
     entry['trace_bytes_per_frame'] = round(tot)              # what bench.py divides by ITS launches per frame
     sh = [v for k, v in entry['kernels'].items() if k.startswith('k_shade')]
     entry['shade_bytes_per_frame'] = round(sum((v.get('fetch_bytes_per_launch', 0) + v.get('write_bytes_per_launch', 0)) * v['launches'] for v in sh))
+    if len(sys.argv) > 4:
+        summ = json.load(open(sys.argv[4]))
+        entry['units'] = {k: {f: v[f] for f in ('valu_issue_share_min', 'ta_busy', 'wait_any_share_of_wave_cycles', 'valu_lane_utilisation', 'tcc_hit_rate') if f in v}
+                          for k, v in summ.items() if k.startswith('k_trace') or k.startswith('k_shade')}
+        entry['units_source'] = os.path.relpath(sys.argv[4], root)
     data[workload] = entry
     json.dump(data, open(path, 'w'), indent=1)
     print(json.dumps(entry, indent=1))
