@@ -114,7 +114,8 @@ typedef struct {
     /* The reference's selectable alternatives (ABI 2).  `main` hard-wires the path integrator with the Sobol sampler
      * (craytracer.rs:159-160, 361); simple_integrator::estimate_Li (src/simple_integrator.rs:36-143: no MIS, no roulette)
      * and UniformSampler (src/sampling.rs:154-194: slot centres, uniform_nx * uniform_ny must equal Scene.num_samples) are
-     * what a maintainer gets by editing those lines.  IndependentSampler (rand's ChaCha12 StdRng) is not provided. */
+     * what a maintainer gets by editing those lines; IndependentSampler (src/sampling.rs:102-146, rand's ChaCha12 StdRng) is
+     * provided too, restated from the crates' published algorithms and NOT pinned against them. */
     uint32_t integrator;        /* CRAY_INTEGRATOR_PATH (default) | CRAY_INTEGRATOR_SIMPLE */
     uint32_t sampler;           /* CRAY_SAMPLER_SOBOL (default) | CRAY_SAMPLER_UNIFORM | CRAY_SAMPLER_INDEPENDENT */
     uint32_t uniform_nx, uniform_ny;

@@ -3,6 +3,10 @@
 //   A  every lane loads its own record with 7 x 16-B loads (what k_trace does): 7 x 64 distinct-line requests per wave step
 //   B  8 lanes load one record with ONE 16-B load each (8 records per load instruction, coalesced per record), the data
 //      goes through LDS to the owning lane: 8 x 8 line requests per wave step + 8 ds_write_b128 + 7 ds_read_b128
+//   C  (round 3) the four lanes of a quad load one record's 64-B half with ONE 16-B load each (coalesced: one L1 access per half
+//      instead of four), the 4 x 4 blocks are transposed inside the quad with DPP moves (no LDS): 8 load instructions of 16
+//      accesses per wave step instead of 7 of 64, paid with ~64 more VALU instructions
+//   D  calibration: per-lane loads of only the first 4 x 16 B of the record (what a 64-B record would cost)
 //   hipcc --offload-arch=gfx950 -O3 -o fetch_pattern tools/fetch_pattern.hip && ./fetch_pattern
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -21,9 +25,12 @@ __device__ __forceinline__ double work(double x, const double2* r, int n_ops) {
     return a;
 }
 
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true); }
+
 template <int MODE>
 __global__ void __launch_bounds__(kBlock, 4) chase(const double2* __restrict__ table, uint32_t n_rec, uint32_t hot_n, uint32_t hot, uint32_t steps, int n_ops, double* out,
-                                                   unsigned long long* sink) {
+                                                   unsigned long long* sink, uint32_t* last_idx) {
     __shared__ double2 stage[(kBlock / 64) * 64 * kRow];
     const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     double2* st = stage + wave * 64 * kRow;
@@ -35,6 +42,97 @@ __global__ void __launch_bounds__(kBlock, 4) chase(const double2* __restrict__ t
             const double2* rec = table + (size_t)idx * 8;
 #pragma unroll
             for (int k = 0; k < 7; k++) r[k] = rec[k];
+        } else if (MODE == 3) {
+            const double2* rec = table + (size_t)idx * 8;
+#pragma unroll
+            for (int k = 0; k < 4; k++) r[k] = rec[k];
+            r[4] = r[0]; r[5] = r[1]; r[6] = r[2];
+            r[6].y = r[3].y;   // calibration table: the successor also sits in the fourth unit
+        } else if (MODE == 4) {
+            // as C, with the select folded into the DPP move (v_cndmask_b32_dpp): 2 instead of 4 VALU instructions per exchanged dword pair
+            const unsigned int j = lane & 3u;
+            uint4 L[4][2];
+            const uint32_t oi[4] = {dpp<0x00>(idx), dpp<0x55>(idx), dpp<0xAA>(idx), dpp<0xFF>(idx)};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint4* rec = reinterpret_cast<const uint4*>(table + (size_t)oi[k] * 8) + j;
+                L[k][0] = rec[0];
+                L[k][1] = rec[4];
+            }
+#define XCH4(A, B, KEEP_A, CTRL)                                                                       \
+            {                                                                                           \
+                uint4 na_, nb_;                                                                         \
+                asm volatile("s_nop 4\n\ts_mov_b64 vcc, %16\n\t"                                       \
+                             "v_cndmask_b32_dpp %0, %12, %8, vcc " CTRL " row_mask:0xf bank_mask:0xf\n\t"  \
+                             "v_cndmask_b32_dpp %1, %13, %9, vcc " CTRL " row_mask:0xf bank_mask:0xf\n\t"  \
+                             "v_cndmask_b32_dpp %2, %14, %10, vcc " CTRL " row_mask:0xf bank_mask:0xf\n\t" \
+                             "v_cndmask_b32_dpp %3, %15, %11, vcc " CTRL " row_mask:0xf bank_mask:0xf\n\t" \
+                             "s_not_b64 vcc, vcc\n\t"                                                   \
+                             "v_cndmask_b32_dpp %4, %8, %12, vcc " CTRL " row_mask:0xf bank_mask:0xf\n\t"  \
+                             "v_cndmask_b32_dpp %5, %9, %13, vcc " CTRL " row_mask:0xf bank_mask:0xf\n\t"  \
+                             "v_cndmask_b32_dpp %6, %10, %14, vcc " CTRL " row_mask:0xf bank_mask:0xf\n\t" \
+                             "v_cndmask_b32_dpp %7, %11, %15, vcc " CTRL " row_mask:0xf bank_mask:0xf"      \
+                             : "=&v"(na_.x), "=&v"(na_.y), "=&v"(na_.z), "=&v"(na_.w), "=&v"(nb_.x), "=&v"(nb_.y), "=&v"(nb_.z), "=&v"(nb_.w) \
+                             : "v"((A).x), "v"((A).y), "v"((A).z), "v"((A).w), "v"((B).x), "v"((B).y), "v"((B).z), "v"((B).w), "s"(KEEP_A)    \
+                             : "vcc", "scc");                                                           \
+                (A) = na_; (B) = nb_;                                                                   \
+            }
+            const unsigned long long keep_even = 0x5555555555555555ull, keep_low = 0x3333333333333333ull;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                XCH4(L[0][h], L[1][h], keep_even, "quad_perm:[1,0,3,2]")
+                XCH4(L[2][h], L[3][h], keep_even, "quad_perm:[1,0,3,2]")
+                XCH4(L[0][h], L[2][h], keep_low, "quad_perm:[2,3,0,1]")
+                XCH4(L[1][h], L[3][h], keep_low, "quad_perm:[2,3,0,1]")
+            }
+#undef XCH4
+#pragma unroll
+            for (int k = 0; k < 7; k++) {
+                const uint4 v = L[k & 3][k >> 2];
+                r[k].x = __hiloint2double((int)v.y, (int)v.x);
+                r[k].y = __hiloint2double((int)v.w, (int)v.z);
+            }
+        } else if (MODE == 2) {
+            // quad-cooperative fetch: load (k, h) reads bytes [64 h, 64 h + 64) of the record of quad lane k, 16 B per lane
+            const unsigned int j = lane & 3u;
+            uint4 L[4][2];
+            const uint32_t oi[4] = {dpp<0x00>(idx), dpp<0x55>(idx), dpp<0xAA>(idx), dpp<0xFF>(idx)};   // quad_perm:[k,k,k,k]
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint4* rec = reinterpret_cast<const uint4*>(table + (size_t)oi[k] * 8) + j;
+                L[k][0] = rec[0];
+                L[k][1] = rec[4];
+            }
+            // 4 x 4 transpose of 16-B blocks inside the quad: two butterfly stages of select + DPP move per dword
+            const bool odd = (lane & 1u) != 0, hi = (lane & 2u) != 0;
+#define XCH(A, B, SEL, CTRL)                                                                              \
+            {                                                                                              \
+                const uint32_t a_ = (A), b_ = (B);                                                         \
+                const uint32_t pa_ = dpp<CTRL>(a_);                                                        \
+                const uint32_t pb_ = dpp<CTRL>(b_);                                                        \
+                (A) = (SEL) ? pb_ : a_;                                                                    \
+                (B) = (SEL) ? b_ : pa_;                                                                    \
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+#pragma unroll
+                for (int a = 0; a < 4; a += 2) {
+                    XCH(L[a][h].x, L[a + 1][h].x, odd, 0xB1) XCH(L[a][h].y, L[a + 1][h].y, odd, 0xB1)
+                    XCH(L[a][h].z, L[a + 1][h].z, odd, 0xB1) XCH(L[a][h].w, L[a + 1][h].w, odd, 0xB1)
+                }
+#pragma unroll
+                for (int m = 0; m < 2; m++) {
+                    XCH(L[m][h].x, L[m + 2][h].x, hi, 0x4E) XCH(L[m][h].y, L[m + 2][h].y, hi, 0x4E)
+                    XCH(L[m][h].z, L[m + 2][h].z, hi, 0x4E) XCH(L[m][h].w, L[m + 2][h].w, hi, 0x4E)
+                }
+            }
+#undef XCH
+#pragma unroll
+            for (int k = 0; k < 7; k++) {
+                const uint4 v = L[k & 3][k >> 2];
+                r[k].x = __hiloint2double((int)v.y, (int)v.x);
+                r[k].y = __hiloint2double((int)v.w, (int)v.z);
+            }
         } else {
 #pragma unroll
             for (int rd = 0; rd < 8; rd++) {
@@ -61,6 +159,7 @@ __global__ void __launch_bounds__(kBlock, 4) chase(const double2* __restrict__ t
         if (acc == 0.12345) idx ^= 1u;
     }
     if (acc == 123.456) out[0] = acc;
+    last_idx[blockIdx.x * kBlock + threadIdx.x] = idx;   // the chain's end: equal in every mode (checked on the host)
     if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(sink, 1ull);
 }
 
@@ -76,23 +175,34 @@ int main() {
         long long bits = (long long)(x & 0xffffffffull);
         double d; __builtin_memcpy(&d, &bits, 8);
         h[i * 8 + 6].y = d;  // successor index in the low 32 bits (a denormal double)
+        h[i * 8 + 3].y = d;  // (mode D reads it from the first half)
     }
     hipMemcpy(table, h.data(), (size_t)n_rec * 128, hipMemcpyHostToDevice);
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int grid = 256 * 4;
+    uint32_t* last; hipMalloc(&last, (size_t)grid * kBlock * 4);
+    std::vector<uint32_t> ref((size_t)grid * kBlock), got((size_t)grid * kBlock);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const uint32_t steps = 2000;
     for (int cfg = 0; cfg < 6; cfg++) {
         const int n_ops = cfg < 3 ? 154 : 308;
         const uint32_t hot = (cfg % 3) * 3;          // 0, 3, 6 of 8 steps hit the 4 MiB hot set
         const uint32_t hot_n = 32768;
-        for (int mode = 0; mode < 2; mode++) {
+        for (int mode = 0; mode < 5; mode++) {
             for (int rep = 0; rep < 2; rep++) {
                 hipEventRecord(e0, 0);
-                if (mode == 0) hipLaunchKernelGGL(chase<0>, dim3(grid), dim3(kBlock), 0, 0, table, n_rec, hot_n, hot, steps, n_ops, out, sink);
-                else hipLaunchKernelGGL(chase<1>, dim3(grid), dim3(kBlock), 0, 0, table, n_rec, hot_n, hot, steps, n_ops, out, sink);
+                if (mode == 0) hipLaunchKernelGGL(chase<0>, dim3(grid), dim3(kBlock), 0, 0, table, n_rec, hot_n, hot, steps, n_ops, out, sink, last);
+                else if (mode == 2) hipLaunchKernelGGL(chase<2>, dim3(grid), dim3(kBlock), 0, 0, table, n_rec, hot_n, hot, steps, n_ops, out, sink, last);
+                else if (mode == 4) hipLaunchKernelGGL(chase<4>, dim3(grid), dim3(kBlock), 0, 0, table, n_rec, hot_n, hot, steps, n_ops, out, sink, last);
+                else if (mode == 3) hipLaunchKernelGGL(chase<3>, dim3(grid), dim3(kBlock), 0, 0, table, n_rec, hot_n, hot, steps, n_ops, out, sink, last);
+                else hipLaunchKernelGGL(chase<1>, dim3(grid), dim3(kBlock), 0, 0, table, n_rec, hot_n, hot, steps, n_ops, out, sink, last);
                 hipEventRecord(e1, 0); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
-                if (rep == 1) printf("hot %u/8 ops/step %3d  mode %s  %.2f ms  %.2f G lane-steps/s\n", hot, n_ops, mode ? "B cooperative+LDS" : "A per-lane       ", ms,
+                if (rep == 1) {
+                    hipMemcpy(got.data(), last, got.size() * 4, hipMemcpyDeviceToHost);
+                    if (mode == 0) ref = got;
+                    else if (got != ref) printf("  MISMATCH: mode %d ends its chains elsewhere than mode A\n", mode);
+                }
+                if (rep == 1) printf("hot %u/8 ops/step %3d  mode %s  %.2f ms  %.2f G lane-steps/s\n", hot, n_ops, mode == 0 ? "A per-lane        " : mode == 1 ? "B cooperative+LDS " : mode == 2 ? "C quad + DPP      " : mode == 4 ? "E quad + cndmask_dpp" : "D per-lane 4 loads", ms,
                                      (double)grid * kBlock * steps / (ms * 1e-3) / 1e9);
             }
         }
