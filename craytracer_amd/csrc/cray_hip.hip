@@ -765,6 +765,27 @@ extern "C" int cray_scene_upload(cray_ctx* c, const cray_flat_scene* f, cray_sce
     double gamma_lut[256];  // Color::from_rgb (color.rs:39-46): (c/255).powf(2.2), libm pow like the reference
     for (int i = 0; i < 256; i++) gamma_lut[i] = pow((double)i / 255.0, 2.2);
 
+    if (resident && !e) {
+        // What fill_slot checks for a scene that brings its tree, checked here for one that does not: the kernels index
+        // spheres[] / disks[] / triangles[] with prims[].shape unchecked, and a sphere / disk without a box of its own would
+        // silently get the all-zero box of k_prim_bounds.
+        std::vector<uint8_t> boxes(f->n_prims, 0);
+        for (uint32_t i = 0; i < f->n_other_bounds && !e; i++) {
+            const cray_prim_bound& b = f->other_bounds[i];
+            if (b.prim >= f->n_prims) { set_last_error("other_bounds[%u]: primitive %u out of range", i, b.prim); e = CRAY_ERR_INVALID; break; }
+            if (f->prims[b.prim].shape_kind == CRAY_SHAPE_TRIANGLE) { set_last_error("other_bounds[%u]: primitive %u is a triangle (its box is computed on the device)", i, b.prim); e = CRAY_ERR_INVALID; break; }
+            if (boxes[b.prim]++) { set_last_error("other_bounds[%u]: primitive %u already has a box", i, b.prim); e = CRAY_ERR_INVALID; break; }
+            for (int k = 0; k < 3; k++)
+                if (!std::isfinite(b.bmin[k]) || !std::isfinite(b.bmax[k])) { set_last_error("other_bounds[%u]: non-finite box of primitive %u", i, b.prim); e = CRAY_ERR_INVALID; }
+        }
+        for (uint32_t i = 0; i < f->n_prims && !e; i++) {
+            const cray_prim& p = f->prims[i];
+            const bool tri = p.shape_kind == CRAY_SHAPE_TRIANGLE, sph = p.shape_kind == CRAY_SHAPE_SPHERE, dsk = p.shape_kind == CRAY_SHAPE_DISK;
+            if (tri && p.shape >= f->n_triangles) { set_last_error("primitive %u: bad triangle index", i); e = CRAY_ERR_INVALID; }
+            else if ((!tri && !sph && !dsk) || (sph && p.shape >= f->n_spheres) || (dsk && p.shape >= f->n_disks)) { set_last_error("primitive %u: bad shape", i); e = CRAY_ERR_INVALID; }
+            else if (!tri && !boxes[i]) { set_last_error("primitive %u: a sphere / disk needs its box in other_bounds (build_on_device)", i); e = CRAY_ERR_INVALID; }
+        }
+    }
     if (resident) {
         if (!e) e = build_resident(c, f, s);   // inner, slots, prims, tri_shade: built on the device, in this order
     } else {
@@ -1623,19 +1644,32 @@ int ensure_all_pix(cray_ctx* c, uint32_t W, uint32_t H, uint32_t tw, uint32_t th
     return CRAY_OK;
 }
 
-// Pack this rank's tiles out of `film` (dividing by `div`), move them to rank 0, and there rebuild the row-major film
-// in `dst` (device).  Collective over the ctx's communicator; c->pix_list must hold this rank's pixel list.
-int gather_tiles(cray_ctx* c, uint32_t W, uint32_t H, uint32_t tw, uint32_t th, const float* film, float div, float* dst) {
-    Rccl* R = rccl();
-    if (!R || !c->comm) { set_last_error("no communicator: call cray_comm_init first"); return CRAY_ERR_INVALID; }
+// Everything of the gather that can fail on ONE rank alone (the tile map, the buffers): done before the ranks agree on
+// their status, so that no rank enters the point-to-point exchange while another has already returned an error.
+int gather_prepare(cray_ctx* c, uint32_t W, uint32_t H, uint32_t tw, uint32_t th) {
+    if (!rccl() || !c->comm) { set_last_error("no communicator: call cray_comm_init first"); return CRAY_ERR_INVALID; }
     const uint32_t world = (uint32_t)c->comm_world, rank = (uint32_t)c->comm_rank;
     const size_t n_mine = c->pix_count;
     int e;
     if (rank == 0) {
         if ((e = ensure_all_pix(c, W, H, tw, th, world))) return e;
         if (c->rank_offset[1] != n_mine) { set_last_error("internal error: rank 0 owns %zu pixels, the map says %zu", n_mine, c->rank_offset[1]); return CRAY_ERR_INVALID; }
+        if ((e = ensure_buffer(&c->gathered, &c->gathered_floats, (size_t)W * H * 3))) return e;
+    } else {
+        if ((e = ensure_buffer(&c->packed, &c->packed_floats, n_mine * 3))) return e;
+    }
+    return CRAY_OK;
+}
+
+// Pack this rank's tiles out of `film` (dividing by `div`), move them to rank 0, and there rebuild the row-major film
+// in `dst` (device).  Collective over the ctx's communicator; c->pix_list must hold this rank's pixel list and
+// gather_prepare + comm_agree must have succeeded on every rank.
+int gather_tiles(cray_ctx* c, uint32_t W, uint32_t H, uint32_t tw, uint32_t th, const float* film, float div, float* dst) {
+    Rccl* R = rccl();
+    const uint32_t world = (uint32_t)c->comm_world, rank = (uint32_t)c->comm_rank;
+    const size_t n_mine = c->pix_count;
+    if (rank == 0) {
         const size_t total = (size_t)W * H;
-        if ((e = ensure_buffer(&c->gathered, &c->gathered_floats, total * 3))) return e;
         // rank 0's own tiles go straight to the head of the gathered buffer
         if (n_mine) hipLaunchKernelGGL(k_pack_tiles, dim3(grid_for(c, n_mine * 3, 8)), dim3(kBlock), 0, c->stream, film, c->pix_list, n_mine, div, c->gathered);
         RCCL_TRY(R, R->GroupStart());
@@ -1646,7 +1680,6 @@ int gather_tiles(cray_ctx* c, uint32_t W, uint32_t H, uint32_t tw, uint32_t th, 
         RCCL_TRY(R, R->GroupEnd());
         hipLaunchKernelGGL(k_unpack_tiles, dim3(grid_for(c, total * 3, 8)), dim3(kBlock), 0, c->stream, (const float*)c->gathered, (const uint32_t*)c->all_pix, total, dst);
     } else {
-        if ((e = ensure_buffer(&c->packed, &c->packed_floats, n_mine * 3))) return e;
         if (n_mine) {
             hipLaunchKernelGGL(k_pack_tiles, dim3(grid_for(c, n_mine * 3, 8)), dim3(kBlock), 0, c->stream, film, c->pix_list, n_mine, div, c->packed);
             RCCL_TRY(R, R->Send(c->packed, n_mine * 3, ncclFloat, 0, c->comm, c->stream));
@@ -1775,17 +1808,34 @@ extern "C" int cray_comm_barrier(cray_ctx* c) {
     return cray_comm_allreduce_f64(c, &one, 1, CRAY_REDUCE_SUM);
 }
 
+// Every rank passes the return code of the work it did alone (0 or a negative CRAY_ERR_*); every rank gets the worst of
+// them.  Real RCCL has no timeout: a rank that returned early from a collective sequence leaves its peers waiting in
+// ncclRecv / ncclBroadcast for ever, so the ranks agree BEFORE any transfer whose other end might be missing.
+static int comm_agree(cray_ctx* c, int local) {
+    if (!c->comm || c->comm_world == 1) return local;
+    char mine[sizeof(g_err)];
+    memcpy(mine, g_err, sizeof(mine));   // the all-reduce below may overwrite the thread's message
+    double v = (double)local;
+    const int e = cray_comm_allreduce_f64(c, &v, 1, CRAY_REDUCE_MIN);
+    if (e) return e;                     // the collective itself failed: nothing to agree with
+    if (local) { memcpy(g_err, mine, sizeof(mine)); return local; }
+    if (v != 0.0) { set_last_error("another rank failed with code %d before the exchange (its own message has the detail)", (int)v); return (int)v; }
+    return CRAY_OK;
+}
+
 extern "C" int cray_scene_broadcast(cray_ctx* c, cray_scene* mine, int root, cray_scene** out) {
     if (!c || !out) { set_last_error("cray_scene_broadcast: null argument"); return CRAY_ERR_INVALID; }
     *out = nullptr;
     const int rank = cray_comm_rank(c), world = cray_comm_world_size(c);
-    if (root < 0 || root >= world) { set_last_error("cray_scene_broadcast: root %d of %d", root, world); return CRAY_ERR_INVALID; }
-    if ((rank == root) != (mine != nullptr)) { set_last_error("cray_scene_broadcast: pass the scene on the root and NULL elsewhere"); return CRAY_ERR_INVALID; }
-    if (mine && (mine->ctx != c || mine->allocs.size() != (size_t)kSceneArrays)) { set_last_error("cray_scene_broadcast: scene does not belong to this context"); return CRAY_ERR_INVALID; }
-    if (world == 1) { *out = mine; return CRAY_OK; }
+    int bad = CRAY_OK;
+    if (root < 0 || root >= world) { set_last_error("cray_scene_broadcast: root %d of %d", root, world); bad = CRAY_ERR_INVALID; }
+    else if ((rank == root) != (mine != nullptr)) { set_last_error("cray_scene_broadcast: pass the scene on the root and NULL elsewhere"); bad = CRAY_ERR_INVALID; }
+    else if (mine && (mine->ctx != c || mine->allocs.size() != (size_t)kSceneArrays)) { set_last_error("cray_scene_broadcast: scene does not belong to this context"); bad = CRAY_ERR_INVALID; }
+    if (world == 1) { if (!bad) *out = mine; return bad; }
     Rccl* R = rccl();
     if (!R) return CRAY_ERR_UNSUPPORTED;
     HIP_TRY(hipSetDevice(c->device));
+    if ((bad = comm_agree(c, bad))) return bad;   // a rank with bad arguments must not leave the others inside ncclBroadcast
     SceneHeader h;
     memset(&h, 0, sizeof(h));
     if (mine) {
@@ -1807,18 +1857,22 @@ extern "C" int cray_scene_broadcast(cray_ctx* c, cray_scene* mine, int root, cra
         s->dev.inner32 = nullptr; s->dev.slots32 = nullptr; s->dev.innerh = nullptr;   // the fast-mode records are derived per rank on first use
         const void** fields[kSceneArrays];
         scene_arrays(s->dev, fields);
-        for (int i = 0; i < kSceneArrays; i++) {
+        for (int i = 0; i < kSceneArrays && !bad; i++) {
             void* d = nullptr;
             hipError_t err = hipMalloc(&d, h.bytes[i]);
             if (err != hipSuccess) {
-                // the other ranks are inside the collective sequence: nothing sensible can continue, but do not leak
                 set_last_error("cray_scene_broadcast: hipMalloc(%llu) failed: %s", (unsigned long long)h.bytes[i], hipGetErrorString(err));
-                cray_scene_free(s);
-                return CRAY_ERR_HIP;
+                bad = CRAY_ERR_HIP;
+                break;
             }
             s->allocs.push_back(d); s->alloc_bytes.push_back(h.bytes[i]); s->bytes += h.bytes[i];
             *fields[i] = d;
         }
+    }
+    // a receiver that could not allocate its copy tells the others before the big transfers start: every rank returns the error
+    if ((bad = comm_agree(c, bad))) {
+        if (!mine) cray_scene_free(s);
+        return bad;
     }
     // the big arrays (2.4 GB at 7.2 M triangles) go root HBM -> peer HBM over xGMI, one broadcast per array
     for (int i = 0; i < kSceneArrays; i++)
@@ -1837,16 +1891,22 @@ extern "C" int cray_render_gather(cray_ctx* c, cray_scene* s, const cray_render_
     }
     cray_render_params prm = *prm_in;
     prm.rank = (uint32_t)c->comm_rank; prm.world_size = (uint32_t)c->comm_world;
-    int e = check_render_args(c, s, &prm);
-    if (e) return e;
-    if (c->comm_rank == 0 && !out_rgb) { set_last_error("cray_render_gather: out_rgb is null on rank 0"); return CRAY_ERR_INVALID; }
     HIP_TRY(hipSetDevice(c->device));
-    const DevScene& d = s->dev;
-    const size_t film_floats = (size_t)d.film_w * d.film_h * 3;
+    // Whatever this rank does alone — argument checks, allocations, the render itself (out of memory, a traversal stack
+    // that overflows, a HIP error) — is done first and its status agreed with the other ranks; only then does the gather start.
+    int e = check_render_args(c, s, &prm);
+    if (!e && c->comm_rank == 0 && !out_rgb) { set_last_error("cray_render_gather: out_rgb is null on rank 0"); e = CRAY_ERR_INVALID; }
+    size_t film_floats = 0;
     float* dst = nullptr;
-    if (c->comm_rank == 0 && (e = output_target(c, &prm, out_rgb, film_floats, &dst))) return e;
     auto t0 = std::chrono::steady_clock::now();
-    if ((e = render_local(c, s, &prm, stats))) return e;
+    if (!e) {
+        film_floats = (size_t)s->dev.film_w * s->dev.film_h * 3;
+        if (c->comm_rank == 0) e = output_target(c, &prm, out_rgb, film_floats, &dst);
+    }
+    if (!e) e = render_local(c, s, &prm, stats);
+    if (!e) e = gather_prepare(c, s->dev.film_w, s->dev.film_h, prm.tile_width, prm.tile_height);
+    if ((e = comm_agree(c, e))) return e;
+    const DevScene& d = s->dev;
     if ((e = gather_tiles(c, d.film_w, d.film_h, prm.tile_width, prm.tile_height, c->film, (float)d.num_samples, dst))) return e;
     if ((e = finish_output(c, &prm, c->comm_rank == 0 ? out_rgb : nullptr, film_floats))) return e;
     if (stats) stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -1862,11 +1922,12 @@ extern "C" int cray_film_gather(cray_ctx* c, uint32_t W, uint32_t H, uint32_t tw
     cray_render_params_default(&prm);
     prm.tile_width = tw; prm.tile_height = th; prm.rank = (uint32_t)c->comm_rank; prm.world_size = (uint32_t)c->comm_world;
     prm.out_is_device = out_is_device ? 1u : 0u;
-    int e;
-    if ((e = ensure_pix_list(c, W, H, prm))) return e;
+    int e = ensure_pix_list(c, W, H, prm);
     const size_t film_floats = (size_t)W * H * 3;
     float* dst = nullptr;
-    if (c->comm_rank == 0 && (e = output_target(c, &prm, out_rgb, film_floats, &dst))) return e;
+    if (!e && c->comm_rank == 0) e = output_target(c, &prm, out_rgb, film_floats, &dst);
+    if (!e) e = gather_prepare(c, W, H, tw, th);
+    if ((e = comm_agree(c, e))) return e;
     if ((e = gather_tiles(c, W, H, tw, th, local_film, 1.0f, dst))) return e;
     return finish_output(c, &prm, c->comm_rank == 0 ? out_rgb : nullptr, film_floats);
 }

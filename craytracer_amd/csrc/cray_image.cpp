@@ -17,6 +17,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <new>
+#include <stdexcept>
 #include <vector>
 
 #include "../../include/cray.h"
@@ -221,6 +223,7 @@ int decode_png(const std::vector<uint8_t>& d, uint32_t* w_out, uint32_t* h_out, 
             if (len < 13) return fail("bad IHDR");
             W = be32(at); H = be32(at + 4); depth = d[at + 8]; ctype = d[at + 9]; interlace = d[at + 12];
             if (d[at + 10] != 0 || d[at + 11] != 0 || interlace > 1) return fail("unsupported compression / filter / interlace method");
+            if ((uint64_t)W * (uint64_t)H > (1ull << 28)) return fail("image too large (more than 2^28 pixels)");
         } else if (!memcmp(ty, "PLTE", 4)) plte.assign(d.begin() + at, d.begin() + at + len);
         else if (!memcmp(ty, "IDAT", 4)) idat.insert(idat.end(), d.begin() + at, d.begin() + at + len);
         else if (!memcmp(ty, "IEND", 4)) seen_end = true;
@@ -394,6 +397,7 @@ struct Jpeg {
     // ---- one block, sequential (baseline) scan
     void block_seq(Comp& c, int16_t* blk) {
         int t = decode(dc[c.dc_tab]);
+        if (t > 11) { err = "bad Huffman code"; return; }   // DC difference categories of 8-bit JPEG: 0..11 (T.81 F.1.2.1.1)
         int diff = t ? extend(getbits(t), t) : 0;
         c.pred += diff;
         blk[0] = (int16_t)c.pred;
@@ -413,6 +417,7 @@ struct Jpeg {
     // ---- progressive scans (ITU T.81 G.1.2)
     void block_dc_first(Comp& c, int16_t* blk, int al) {
         int t = decode(dc[c.dc_tab]);
+        if (t > 11) { err = "bad Huffman code"; return; }
         int diff = t ? extend(getbits(t), t) : 0;
         c.pred += diff;
         blk[0] = (int16_t)(c.pred * (1 << al));
@@ -502,6 +507,7 @@ struct Jpeg {
     }
 
     bool scan(size_t at, size_t len) {
+        if (len < 1) { err = "bad SOS"; return false; }   // (a file that ends in FF DA 00 02 has at == n here)
         const int ns = d[at];
         if (ns < 1 || ns > 4 || len < (size_t)(1 + 2 * ns + 3)) { err = "bad SOS"; return false; }
         int idx[4];
@@ -611,6 +617,7 @@ struct Jpeg {
                 progressive = m == 0xc2;
                 H = u16(at + 1); W = u16(at + 3); ncomp = d[at + 5];
                 if (W < 1 || H < 1 || (ncomp != 1 && ncomp != 3) || body < (size_t)(6 + 3 * ncomp)) { err = "unsupported frame (need 1 or 3 components)"; return false; }
+                if ((uint64_t)W * (uint64_t)H > (1ull << 28)) { err = "image too large (more than 2^28 pixels)"; return false; }
                 for (int i = 0; i < ncomp; i++) {
                     Comp& c = comp[i];
                     c.id = d[at + 6 + 3 * i]; c.h = d[at + 7 + 3 * i] >> 4; c.v = d[at + 7 + 3 * i] & 15; c.tq = d[at + 8 + 3 * i];
@@ -815,14 +822,26 @@ int decode_jpeg(const std::vector<uint8_t>& d, uint32_t* w, uint32_t* h, uint8_t
 extern "C" int cray_load_image(const char* path, uint32_t* width, uint32_t* height, uint8_t** rgb8) {
     if (!path || !width || !height || !rgb8) { cray::set_last_error("cray_load_image: null argument"); return CRAY_ERR_INVALID; }
     *rgb8 = nullptr;
-    std::vector<uint8_t> d;
-    if (!read_whole_file(path, d)) { cray::set_last_error("cray_load_image: cannot read %s", path); return CRAY_ERR_INVALID; }
-    if (d.size() >= 8 && d[0] == 'P' && (d[1] == '2' || d[1] == '3' || d[1] == '5' || d[1] == '6')) return decode_pnm(d, width, height, rgb8);
-    if (d.size() >= 4 && d[0] == 0xff && d[1] == 0xd8) return decode_jpeg(d, width, height, rgb8);
-    static const uint8_t png_sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
-    if (d.size() >= 8 && memcmp(d.data(), png_sig, 8) == 0) return decode_png(d, width, height, rgb8);
-    cray::set_last_error("cray_load_image: %s is not PNM, PNG or JPEG (other formats need a caller-supplied cray_image_loader)", path);
-    return CRAY_ERR_UNSUPPORTED;
+    // Nothing may leave an extern "C" function by exception: a header that declares 65535 x 65535 pixels makes the decoders'
+    // vectors throw std::bad_alloc, which would reach std::terminate in a C, Rust or ctypes host.
+    try {
+        std::vector<uint8_t> d;
+        if (!read_whole_file(path, d)) { cray::set_last_error("cray_load_image: cannot read %s", path); return CRAY_ERR_INVALID; }
+        if (d.size() >= 8 && d[0] == 'P' && (d[1] == '2' || d[1] == '3' || d[1] == '5' || d[1] == '6')) return decode_pnm(d, width, height, rgb8);
+        if (d.size() >= 4 && d[0] == 0xff && d[1] == 0xd8) return decode_jpeg(d, width, height, rgb8);
+        static const uint8_t png_sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+        if (d.size() >= 8 && memcmp(d.data(), png_sig, 8) == 0) return decode_png(d, width, height, rgb8);
+        cray::set_last_error("cray_load_image: %s is not PNM, PNG or JPEG (other formats need a caller-supplied cray_image_loader)", path);
+        return CRAY_ERR_UNSUPPORTED;
+    } catch (const std::bad_alloc&) {
+        if (*rgb8) { free(*rgb8); *rgb8 = nullptr; }
+        cray::set_last_error("cray_load_image: %s needs more memory than is available (corrupt header?)", path);
+        return CRAY_ERR_INVALID;
+    } catch (const std::exception& ex) {
+        if (*rgb8) { free(*rgb8); *rgb8 = nullptr; }
+        cray::set_last_error("cray_load_image: %s: %s", path, ex.what());
+        return CRAY_ERR_INVALID;
+    }
 }
 
 extern "C" void cray_free_image(uint8_t* rgb8) { free(rgb8); }

@@ -158,6 +158,33 @@ def test_several_ranks_on_one_gpu_through_the_mock_transport(tmp_path, world):
     c.close()
 
 
+@pytest.mark.parametrize('world', [2, 3])
+def test_a_failing_rank_fails_every_rank_instead_of_hanging_them(tmp_path, world):
+    """Real RCCL has no timeout: a rank that returns early from cray_render_gather / cray_scene_broadcast (bad arguments, out of
+    memory, a HIP error in its render) would leave rank 0 waiting in ncclRecv for ever.  The ranks therefore agree on their
+    status (one-word all-reduce) before any transfer; here rank 1 is made to fail locally and EVERY rank must come back with
+    an error, within the timeout, and the communicator must still render a correct frame afterwards."""
+    backend.lib()
+    so = str(tmp_path / 'libmock_rccl.so')
+    subprocess.check_call(['hipcc', '-std=c++17', '-O2', '-fPIC', '-shared', '-o', so,
+                           os.path.join(ROOT, 'tests', 'mock_rccl', 'mock_rccl.cpp'), '-lrt'], stderr=subprocess.DEVNULL)
+    env = dict(os.environ, CRAY_RCCL_LIB=so)
+    worker = os.path.join(ROOT, 'tests', 'mock_rccl', 'worker_fail.py')
+    id_path = str(tmp_path / 'comm.id')
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), id_path], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError('a rank was left waiting for a peer that had already failed')
+        outs.append(out)
+    assert all(p.returncode == 0 for p in procs), '\n'.join(outs)
+
+
 def test_bench_with_two_ranks_as_the_driver_launches_it(tmp_path):
     """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` — the driver's command for N = 2 — on the one GPU
     of this box, the collective library replaced by the shared-memory stand-in: the id exchange over the rendezvous store,
