@@ -13,9 +13,10 @@ the launcher's rendezvous store that carries the 128-byte communicator id.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel family (BVH traversal, k_trace*):
-algorithmic bytes / HIP-event time of those launches over the timed steps, next to the HBM bytes
-the PMC counters saw (profiles/hbm_traffic.json, from separate rocprofv3 --pmc passes).  `cpu_baseline`
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel family (BVH traversal, k_trace*): `frac` =
+HBM bytes the PMC counters saw per launch (profiles/hbm_traffic.json, separate rocprofv3 --pmc passes of THIS build, refused
+when the committed profile is of another build) / live HIP-event time per launch / 8 TB/s; the algorithmic bytes of
+SURVEY.md 8(d) and the rate they imply sit beside it under their own keys (`alg_bytes_*`).  `cpu_baseline`
 is the CPU oracle (a C++ restatement of the reference path; the Rust reference cannot be built
 here) on a bounded sample of the same workload.
 """
@@ -220,36 +221,51 @@ def main():
         launches_per_frame = k_launches / max(1, args.steps)
         avg_ms = k_ms / max(1.0, k_launches)
         achieved = (alg_bytes_frame * args.steps) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        # HBM bytes the PMC counters saw for these kernels: NOT measured by this run (counters need their own rocprofv3
-        # --pmc passes); taken from the committed summary, whose provenance travels with the number
-        traffic, provenance = None, None
+        # HBM bytes the PMC counters saw for these kernels.  Counters need their own rocprofv3 --pmc passes, so this run cannot
+        # measure them: they come from the committed profile of THIS build (tools/profile_round.sh -> profiles/hbm_traffic.json),
+        # and are refused when the profile is of another build (source hash of the kernels differs from the loaded library's).
+        traffic, provenance, ent = None, None, {}
         tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
-        if os.path.exists(tpath) and world == 1:
+        lib_hash = hip_build.loaded_hash()   # of the library this process runs (its stamp), not of whatever the tree holds now
+        if os.path.exists(tpath):
             try:
                 ent = json.load(open(tpath)).get(args.workload, {})
+            except Exception:
+                ent = {}
+        if ent and world == 1 and args.precision == 'f64':
+            provenance = {'file': 'profiles/hbm_traffic.json', 'pmc_csv': ent.get('source'), 'profiled_source_hash': (ent.get('source_hash') or '')[:16],
+                          'library_source_hash': lib_hash[:16], 'profiled_git': ent.get('git'),
+                          'method': 'FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 from separate rocprofv3 --pmc passes (tools/traffic_from_pmc.py)'}
+            if ent.get('source_hash') == lib_hash:
                 # per launch of THIS run: the profiled frame's traversal traffic over this run's launches per frame (the pass
                 # plan, hence the number of launches, depends on the path pool; the bytes per frame do not)
-                per_frame = ent.get('trace_bytes_per_frame') or (ent.get('trace_bytes_per_launch', 0) * ent.get('trace_launches', 0))
+                per_frame = ent.get('trace_bytes_per_frame') or 0
                 traffic = round(per_frame / max(1.0, launches_per_frame)) if per_frame else None
-                provenance = {'file': 'profiles/hbm_traffic.json', 'pmc_csv': ent.get('source'), 'profiled_build': ent.get('git'),
-                              'method': 'FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 from separate rocprofv3 --pmc passes (tools/traffic_from_pmc.py)'}
-            except Exception:
-                traffic = None
+            else:
+                provenance['refused'] = 'the committed counters are of another build of the kernels: re-run tools/profile_round.sh'
+        hbm_gbs = traffic / (avg_ms * 1e-3) / 1e9 if traffic and avg_ms > 0 else None
         roofline = {'bound': 'hbm',
-                    'bound_note': 'north_star prices this path against the HBM roofline; the PMC counters show the kernel is limited by '
-                                  'dependent L2/TA fetch latency and f64 VALU issue, not by HBM bandwidth (hbm_counter_frac; DESIGN.md §3.1)',
-                    'kernel': 'k_trace family (k_trace<closest> + k_trace_mixed + k_trace<any>)', 'achieved': round(achieved, 2),
-                    'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
+                    'kernel': 'k_trace family (k_trace<closest> + k_trace_mixed + k_trace<any>)',
+                    # achieved / frac: HBM bytes the counters saw per launch over the live HIP-event time of a launch, against the
+                    # 8 TB/s spec.  null when no counter profile of this build is committed (never an algorithmic figure).
+                    'achieved': round(hbm_gbs, 1) if hbm_gbs else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': round(hbm_gbs / HBM_PEAK_GBS, 5) if hbm_gbs else None, 'traffic': traffic,
                     'traffic_provenance': provenance,
-                    'hbm_counter_GBs': round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic and avg_ms > 0 else None,
-                    'hbm_counter_frac': round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic and avg_ms > 0 else None,
-                    'alg_bytes_per_launch': round(alg_bytes_frame / max(1.0, launches_per_frame)),
                     'avg_launch_ms': round(avg_ms, 4), 'launches_per_step': launches_per_frame,
-                    'bytes_per_ray': round(alg_bytes_frame / max(1, traced), 1)}
-        if provenance and ent.get('units'):
-            # what else the same profiled build showed per kernel (separate --pmc passes): lower bound of the share of time the SIMDs
-            # issue VALU work, texture-addresser busy share, share of wave-cycles waiting — the units that do bound this path
-            roofline['other_units'] = {'source': ent.get('units_source'), 'kernels': ent['units']}
+                    # the algorithmic bytes of SURVEY.md section 8(d) (counted, not estimated) and the rate they would need if none of
+                    # them were served by L2 / Infinity Cache: a work measure, NOT a bandwidth the chip delivered
+                    'alg_bytes_per_launch': round(alg_bytes_frame / max(1.0, launches_per_frame)),
+                    'alg_bytes_rate_GBs': round(achieved, 2), 'alg_bytes_per_ray': round(alg_bytes_frame / max(1, traced), 1),
+                    'alg_over_traffic': round(alg_bytes_frame / max(1.0, launches_per_frame) / traffic, 2) if traffic else None,
+                    'bound_note': 'HBM is the roofline the north star prices this path against; the counters of the same build say the units that '
+                                  'bind it are the texture addresser (16-B lane loads of 128-B records) and f64 VALU issue: other_bounds'}
+        if traffic and ent.get('units'):
+            # utilisations of the units that do bind the path, from the SQ / TA passes of the same profiled build (each <= 1)
+            u = ent['units']
+            roofline['other_bounds'] = {'source': ent.get('units_source'), 'kernels': {
+                k: {'ta_busy_share': v.get('ta_busy'), 'valu_issue_share_min': v.get('valu_issue_share_min'),
+                    'valu_lane_utilisation': v.get('valu_lane_utilisation'), 'wait_share_of_wave_cycles': v.get('wait_any_share_of_wave_cycles'),
+                    'l2_hit_rate': v.get('tcc_hit_rate')} for k, v in u.items()}}
         # the second kernel of the frame: k_shade (path state + shading records)
         n_shaded = cst['closest_rays']                      # every traced segment is shaded once
         n_hit = cst.get('closest_hits', 0) or n_shaded      # segments that hit something
@@ -259,7 +275,11 @@ def main():
         shade_ms, shade_launches = kern[5], kern[7]
         if shade_ms > 0:
             sh = shade_bytes * args.steps / (shade_ms * 1e-3) / 1e9
-            roofline['k_shade'] = {'achieved': round(sh, 2), 'unit': 'GB/s', 'frac': round(sh / HBM_PEAK_GBS, 5),
+            sh_traffic = ent.get('shade_bytes_per_frame') if traffic else None   # same profile, same refusal rule
+            sh_gbs = sh_traffic * args.steps / (shade_ms * 1e-3) / 1e9 if sh_traffic else None
+            roofline['k_shade'] = {'achieved': round(sh_gbs, 1) if sh_gbs else None, 'unit': 'GB/s', 'frac': round(sh_gbs / HBM_PEAK_GBS, 5) if sh_gbs else None,
+                                   'traffic': round(sh_traffic * args.steps / max(1.0, shade_launches)) if sh_traffic else None,
+                                   'alg_bytes_rate_GBs': round(sh, 2),
                                    'alg_bytes_per_launch': round(shade_bytes * args.steps / max(1.0, shade_launches)),
                                    'avg_launch_ms': round(shade_ms / max(1.0, shade_launches), 4),
                                    'launches_per_step': shade_launches / max(1, args.steps)}
@@ -270,7 +290,8 @@ def main():
         try:
             stream_gbs = ctx.measure_stream_read(4 << 30, 5)
             roofline['measured_stream_read_GBs'] = round(stream_gbs, 1)
-            roofline['frac_of_measured_stream'] = round(roofline['achieved'] / stream_gbs, 5)
+            if roofline['achieved']:
+                roofline['frac_of_measured_stream'] = round(roofline['achieved'] / stream_gbs, 5)
         except Exception as e:  # measurement aid only
             log('stream-read measurement skipped: %s' % e)
 
@@ -282,12 +303,24 @@ def main():
         oracle_lib.set_libm_mode(1)   # the platform libm's sin/cos, like the reference binary (not the binary128 checker mode)
         orc = oracle_lib.OracleScene(scene)
         cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-        _, ost = orc.render(seed=0, threads=cores, sample_range=(0, 1))
+        # A bounded sample that still loads every thread evenly: whole pixels' first samples of the same frame, cut into
+        # square tiles small enough for >= 16 jobs per thread (the reference gets its job count from 64x64 tiles x 8-sample
+        # batches: 4 080 jobs for this frame).  One sample first to size the run, then as many samples as fit ~20 s.
+        tile = 64
+        while tile > 8 and ((W + tile - 1) // tile) * ((H + tile - 1) // tile) < 16 * cores:
+            tile //= 2
+        jobs = ((W + tile - 1) // tile) * ((H + tile - 1) // tile)
+        oracle_lib.set_tile(tile)
+        _, probe = orc.render(seed=0, threads=cores, sample_range=(0, 1))
+        n_s = int(max(1, min(8, wl['spp'], 20.0 / max(probe['seconds'], 1e-3))))
+        _, ost = orc.render(seed=0, threads=cores, sample_range=(0, n_s)) if n_s > 1 else (None, probe)
+        oracle_lib.set_tile(0)
         oracle_lib.set_libm_mode(0)
         cpu_rays = ost['closest_rays'] + ost['shadow_rays']
         cpu = {'value': round(cpu_rays / ost['seconds'] / 1e6, 3), 'unit': 'Mray/s', 'cores': cores, 'kind': 'port',
-               'sample': '1 of %d spp of the same %dx%d frame (%d rays, %.1f s); C++ restatement of the reference CPU path (-O2, glibc sin/cos), '
-                         'the Rust reference is not buildable here' % (wl['spp'], W, H, cpu_rays, ost['seconds'])}
+               'sample': '%d of %d spp of the same %dx%d frame (%d rays, %.1f s) in %d tile jobs of %dx%d pixels = %.1f jobs per thread, dynamically '
+                         'scheduled; C++ restatement of the reference CPU path (-O2, glibc sin/cos), the Rust reference is not buildable here'
+                         % (n_s, wl['spp'], W, H, cpu_rays, ost['seconds'], jobs, tile, tile, jobs / cores)}
         log('cpu baseline: %.2f Mray/s on %d threads (oracle build %.1fs)' % (cpu['value'], cores, time.time() - tb - ost['seconds']))
 
     if rank == 0:
@@ -308,7 +341,8 @@ def main():
                        'mpaths_per_s': round(total_paths / elapsed / 1e6, 2),
                        'rays_per_frame': int(total_rays / args.steps),
                        'reference_queries_per_frame': int(total_queries / args.steps),
-                       'build': {'libcray_hip': 'stale' if hip_build.stale() else 'current', 'mode': backend.BUILD_MODE}},
+                       'build': {'libcray_hip': 'stale' if hip_build.stale() else 'current', 'mode': backend.BUILD_MODE,
+                                 'source_hash': hip_build.loaded_hash()}},
             'roofline': roofline, 'cpu_baseline': cpu,
             'kernel_ms_per_step': {'trace': round(kern[0] / args.steps, 2), 'trace_closest_bounce0': round(kern[2] / args.steps, 2),
                                    'trace_mixed': round(kern[3] / args.steps, 2), 'trace_any_last_bounce': round(kern[4] / args.steps, 2),

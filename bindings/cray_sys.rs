@@ -483,6 +483,8 @@ extern "C" {
                           film: *const f32, packed: *mut f32, n_pixels: *mut u64) -> c_int;
     pub fn cray_film_unpack(ctx: *mut CrayCtx, width: u32, height: u32, tile_width: u32, tile_height: u32, world_size: u32,
                             gathered: *const f32, out: *mut f32) -> c_int;
+    pub fn cray_tile_pixels(width: u32, height: u32, tile_width: u32, tile_height: u32, rank: u32, world_size: u32,
+                            out: *mut u32, capacity: u64, n_pixels: *mut u64) -> c_int;
     pub fn cray_measure_stream_read(ctx: *mut CrayCtx, bytes: u64, repeats: c_int, gb_per_s: *mut f64) -> c_int;
     pub fn cray_last_error() -> *const c_char;
 

@@ -86,7 +86,7 @@ ABI_SYMBOLS = ['cray_ctx_create', 'cray_ctx_destroy', 'cray_scene_upload', 'cray
                'cray_scene_info', 'cray_comm_unique_id', 'cray_comm_init', 'cray_comm_rank', 'cray_comm_world_size',
                'cray_comm_barrier', 'cray_comm_allreduce_f64', 'cray_scene_broadcast', 'cray_render_gather',
                'cray_film_gather', 'cray_film_pack', 'cray_film_unpack', 'cray_measure_stream_read', 'cray_load_image', 'cray_free_image', 'cray_default_image_loader', 'cray_set_sobol_vectors',
-               'cray_host_scene_new_resident', 'cray_scene_build_stats', 'cray_preview_checkerboard', 'cray_preview_pixels']
+               'cray_host_scene_new_resident', 'cray_scene_build_stats', 'cray_tile_pixels', 'cray_preview_checkerboard', 'cray_preview_pixels']
 
 _lib = None
 #: how the loaded library came to be: 'shipped' (the .so in the tree was current), 'rebuilt' (sources were newer, hipcc ran),
@@ -195,6 +195,17 @@ def lib():
 def _check(code, what):
     if code != 0:
         raise CrayError('%s failed (%d): %s' % (what, code, lib().cray_last_error().decode()))
+
+
+def tile_pixels(width, height, rank, world_size, tile=(64, 64)):
+    """cray_tile_pixels: the pixels (y*W + x) rank `rank` of `world_size` renders, in pack / send order.  Host only: no GPU."""
+    n = C.c_uint64(0)
+    L = lib()
+    L.cray_tile_pixels.argtypes = [C.c_uint32] * 6 + [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    _check(L.cray_tile_pixels(width, height, tile[0], tile[1], rank, world_size, None, 0, C.byref(n)), 'cray_tile_pixels')
+    out = np.zeros(n.value, dtype=np.uint32)
+    _check(L.cray_tile_pixels(width, height, tile[0], tile[1], rank, world_size, out.ctypes.data, len(out), C.byref(n)), 'cray_tile_pixels')
+    return out
 
 
 class HostScene:

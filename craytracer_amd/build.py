@@ -29,6 +29,15 @@ def source_hash():
     return h.hexdigest()
 
 
+def loaded_hash():
+    """Source hash the shipped libcray_hip.so was built from (its stamp); the tree's hash when there is no stamp."""
+    try:
+        with open(STAMP) as fh:
+            return fh.read().strip()
+    except OSError:
+        return source_hash()
+
+
 def stale():
     """True when libcray_hip.so was not built from the sources in the tree (by content, not by mtime)."""
     if not os.path.exists(SO) or not os.path.exists(STAMP):

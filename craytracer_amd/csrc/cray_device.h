@@ -7,7 +7,11 @@
 //  * Triangles are re-ordered into leaf order ("slots"); a slot is one 80-byte record
 //    (v0,e1,e2 + primitive id) = five 16-B loads per lane.
 //  * Shading data (normals / uvs) stays in primitive order, touched once per closest hit.
-//  * Path state is SoA over path slots so that wave loads are coalesced.
+//  * Path state is SoA over path slots so that wave loads are coalesced — and it is RE-COMPACTED every bounce (round 3): k_shade
+//    reads the state of bounce b from one buffer and writes the surviving paths' state into the other at
+//    slot = tile * tile_size + rank-within-tile, so the survivors of a tile are contiguous again (a sparse survivor set in a
+//    fixed per-path layout makes every 8-B lane access its own 64-B sector: the texture addresser, not the VALU, then
+//    bounds k_shade at the later bounces).  Shadow rays get their own compacted buffer; L stays per original path.
 #pragma once
 
 #include "../../include/cray.h"
@@ -134,18 +138,26 @@ struct DevScene {
     const uint16_t* sobol;  // [64][16][4] bit-reversed direction vectors
 };
 
-// Per-path state, SoA over `capacity` path slots.
+// A VIEW of the path state, SoA: three index spaces share one struct of pointers.
+//   live slots   (ox .. hv, hprim, br .. bb, prev_pdf, hash, flags, p0): the paths alive at one bounce, compacted per k_shade
+//                tile; two such buffers alternate (k_shade reads bounce b from one, writes bounce b + 1 into the other).  At
+//                bounce 0 the live slot of a path is its original index (k_raygen), p0 is not read.
+//   shadow slots (sox .. stmax, cr .. cb, sp0, sprim): the shadow rays of one bounce, compacted the same way.
+//   original path index p0 = pixel-in-pass * spp_pass + sample (lr, lg, lb): what k_film sums.
 struct PathState {
     double *ox, *oy, *oz, *dx, *dy, *dz;   // current ray (tmax is +inf for path segments)
     double *br, *bg, *bb;                  // beta
-    double *lr, *lg, *lb;                  // L
+    double *lr, *lg, *lb;                  // L, per ORIGINAL path
     double* prev_pdf;                      // prev_bsdf_pdf
     double *ht, *hu, *hv;                  // closest hit: distance, triangle barycentrics
-    int32_t* hprim;                        // closest hit primitive (-1 = miss)
+    int32_t* hprim;                        // closest hit primitive (-1 = miss); before the trace of a bounce: the primitive the segment starts on
     double *sox, *soy, *soz, *sdx, *sdy, *sdz, *stmax;  // shadow ray
     double *cr, *cg, *cb;                  // NEE contribution added if the shadow ray is unoccluded
     uint32_t* hash;                        // per-pixel Sobol seed (SipHash-1-3)
     uint32_t* flags;                       // bit0: is_specular_bounce
+    uint32_t* p0;                          // live slot -> original path index
+    uint32_t* sp0;                         // shadow slot -> original path index (where the NEE term is added)
+    int32_t* sprim;                        // shadow slot -> primitive the shadow ray starts on (f32 fast mode only reads it)
 };
 
 struct Counters {

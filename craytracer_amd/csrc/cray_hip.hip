@@ -63,7 +63,8 @@ struct cray_ctx {
     // path-state pool
     size_t capacity = 0;
     std::vector<void*> state_allocs;
-    PathState ps{};
+    PathState ps{};       // view 0: live buffer 0 + the shadow buffer + L (k_raygen, bounce 0, the cray_trace hook)
+    PathState ps1{};      // view 1: live buffer 1 + the same shadow buffer and L
     uint32_t* queue[2] = {nullptr, nullptr};
     uint32_t* shadow_queue = nullptr;
     // third stack level (Counters::deep_*), allocated after a frame overflowed LDS + scratch
@@ -73,6 +74,7 @@ struct cray_ctx {
     size_t deep_threads = 0;
     int hybrid = 0;     // certified f32 culling in the exact traversal: opt-in (CRAY_HYBRID=1), same results, not faster as measured
     int mix_trace = 1;  // shadow rays of bounce b and segments of bounce b+1 in one launch (CRAY_MIX_TRACE=0 disables)
+    int log_queues = 0; // CRAY_LOG_QUEUES=1 (diagnostics): after every bounce, sync and print the queue lengths to stderr
     Counters* counters = nullptr;
     uint32_t* pix_list = nullptr;
     size_t pix_capacity = 0;
@@ -132,6 +134,10 @@ int upload(cray_scene* s, const T* host, size_t n, const T** out) {
     return CRAY_OK;
 }
 
+// Bytes of path state per path of a pass: two live buffers (13 f64 + 4 words each), the shadow buffer (10 f64 + 2 words),
+// L (3 f64) and three queues.
+constexpr size_t kBytesPerPath = 2 * (13 * 8 + 4 * 4) + (10 * 8 + 2 * 4) + 3 * 8 + 3 * 4;
+
 int ensure_state(cray_ctx* c, size_t capacity) {
     if (c->capacity >= capacity) return CRAY_OK;
     for (void* p : c->state_allocs) (void)hipFree(p);
@@ -142,21 +148,31 @@ int ensure_state(cray_ctx* c, size_t capacity) {
         c->state_allocs.push_back(*out);
         return CRAY_OK;
     };
-    double** f64s[] = {&c->ps.ox, &c->ps.oy, &c->ps.oz, &c->ps.dx, &c->ps.dy, &c->ps.dz, &c->ps.br, &c->ps.bg, &c->ps.bb,
-                       &c->ps.lr, &c->ps.lg, &c->ps.lb, &c->ps.prev_pdf, &c->ps.ht, &c->ps.hu, &c->ps.hv,
-                       &c->ps.sox, &c->ps.soy, &c->ps.soz, &c->ps.sdx, &c->ps.sdy, &c->ps.sdz, &c->ps.stmax,
-                       &c->ps.cr, &c->ps.cg, &c->ps.cb};
-    for (double** f : f64s) {
-        int r = alloc(capacity * sizeof(double), (void**)f);
-        if (r) return r;
-    }
+    // k_shade compacts per tile: slots run up to (number of tiles) x (tile size) <= paths + one tile
+    const size_t slots = capacity + kShadeTile;
     int r;
-    if ((r = alloc(capacity * 4, (void**)&c->ps.hprim))) return r;
-    if ((r = alloc(capacity * 4, (void**)&c->ps.hash))) return r;
-    if ((r = alloc(capacity * 4, (void**)&c->ps.flags))) return r;
-    if ((r = alloc(capacity * 4, (void**)&c->queue[0]))) return r;
-    if ((r = alloc(capacity * 4, (void**)&c->queue[1]))) return r;
-    if ((r = alloc(capacity * 4, (void**)&c->shadow_queue))) return r;
+    for (PathState* v : {&c->ps, &c->ps1}) {
+        double** live[] = {&v->ox, &v->oy, &v->oz, &v->dx, &v->dy, &v->dz, &v->br, &v->bg, &v->bb, &v->prev_pdf, &v->ht, &v->hu, &v->hv};
+        for (double** f : live)
+            if ((r = alloc(slots * sizeof(double), (void**)f))) return r;
+        if ((r = alloc(slots * 4, (void**)&v->hprim))) return r;
+        if ((r = alloc(slots * 4, (void**)&v->hash))) return r;
+        if ((r = alloc(slots * 4, (void**)&v->flags))) return r;
+        if ((r = alloc(slots * 4, (void**)&v->p0))) return r;
+    }
+    double** shared[] = {&c->ps.lr, &c->ps.lg, &c->ps.lb, &c->ps.sox, &c->ps.soy, &c->ps.soz, &c->ps.sdx, &c->ps.sdy, &c->ps.sdz, &c->ps.stmax,
+                         &c->ps.cr, &c->ps.cg, &c->ps.cb};
+    for (double** f : shared)
+        if ((r = alloc(slots * sizeof(double), (void**)f))) return r;
+    if ((r = alloc(slots * 4, (void**)&c->ps.sp0))) return r;
+    if ((r = alloc(slots * 4, (void**)&c->ps.sprim))) return r;
+    // the second view shares the shadow buffer and L
+    c->ps1.lr = c->ps.lr; c->ps1.lg = c->ps.lg; c->ps1.lb = c->ps.lb;
+    c->ps1.sox = c->ps.sox; c->ps1.soy = c->ps.soy; c->ps1.soz = c->ps.soz; c->ps1.sdx = c->ps.sdx; c->ps1.sdy = c->ps.sdy; c->ps1.sdz = c->ps.sdz;
+    c->ps1.stmax = c->ps.stmax; c->ps1.cr = c->ps.cr; c->ps1.cg = c->ps.cg; c->ps1.cb = c->ps.cb; c->ps1.sp0 = c->ps.sp0; c->ps1.sprim = c->ps.sprim;
+    if ((r = alloc(slots * 4, (void**)&c->queue[0]))) return r;
+    if ((r = alloc(slots * 4, (void**)&c->queue[1]))) return r;
+    if ((r = alloc(slots * 4, (void**)&c->shadow_queue))) return r;
     c->capacity = capacity;
     return CRAY_OK;
 }
@@ -301,6 +317,7 @@ extern "C" int cray_ctx_create(int device_id, void* stream, cray_ctx** out) {
     };
     c->mix_trace = env_int("CRAY_MIX_TRACE", 0, 1, c->mix_trace);
     c->hybrid = env_int("CRAY_HYBRID", 0, 1, c->hybrid);
+    c->log_queues = env_int("CRAY_LOG_QUEUES", 0, 1, 0);
     c->refill_min = (unsigned int)env_int("CRAY_REFILL_MIN", 1, 64, (int)c->refill_min);
     c->refill_min_b0 = (unsigned int)env_int("CRAY_REFILL_MIN_B0", 1, 64, (int)c->refill_min_b0);
     c->refill_min_any = (unsigned int)env_int("CRAY_REFILL_MIN_ANY", 1, 64, (int)c->refill_min_any);
@@ -896,6 +913,30 @@ std::vector<uint32_t> rank_pixels(uint32_t W, uint32_t H, const cray_render_para
     return pix;
 }
 
+}  // namespace
+
+// The shard map itself, for hosts with their own transport and for tests without a GPU (no context needed): the pixels
+// rank `rank` of `world_size` renders, in the order cray_film_pack packs them / cray_render_gather sends them.
+extern "C" int cray_tile_pixels(uint32_t W, uint32_t H, uint32_t tw, uint32_t th, uint32_t rank, uint32_t world, uint32_t* out, uint64_t capacity,
+                                uint64_t* n_pixels) {
+    if (!n_pixels || W == 0 || H == 0 || tw == 0 || th == 0 || world == 0 || rank >= world || (uint64_t)W * H >= (1ull << 32)) {
+        set_last_error("cray_tile_pixels: bad argument");
+        return CRAY_ERR_INVALID;
+    }
+    cray_render_params p;
+    cray_render_params_default(&p);
+    p.tile_width = tw; p.tile_height = th; p.rank = rank; p.world_size = world;
+    const std::vector<uint32_t> pix = rank_pixels(W, H, p);
+    *n_pixels = pix.size();
+    if (out) {
+        if (capacity < pix.size()) { set_last_error("cray_tile_pixels: %llu pixels do not fit a buffer of %llu", (unsigned long long)pix.size(), (unsigned long long)capacity); return CRAY_ERR_INVALID; }
+        if (!pix.empty()) memcpy(out, pix.data(), pix.size() * sizeof(uint32_t));
+    }
+    return CRAY_OK;
+}
+
+namespace {
+
 // The 64-B f32 interior records of the fast mode (bounds rounded outward), derived on the device from the f64 layout.
 int ensure_inner32(cray_ctx* c, cray_scene* s) {
     if (s->dev.inner32) return CRAY_OK;
@@ -994,6 +1035,9 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
     } while (0)
     const unsigned int trace_all = prm.count_traversal == 1 ? 1u : 0u;  // 2 = count, but keep skipping zero-term shadow rays
     for (uint32_t b = 0; b < d.max_depth; b++) {
+        // live state of bounce b sits in view b & 1 (k_raygen wrote view 0), k_shade moves the survivors to the other one
+        const PathState& ps_b = (b & 1) ? c->ps1 : c->ps;
+        const PathState& ps_n = (b & 1) ? c->ps : c->ps1;
         const uint32_t* q = b == 0 ? nullptr : c->queue[b & 1];
         const unsigned int* nq = b == 0 ? nullptr : &ctr->n_active[b & 1];
         uint32_t* q_next = c->queue[(b + 1) & 1];
@@ -1006,9 +1050,9 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
         if (!mixed || b == 0) {
             HIP_TRY(hipMemsetAsync(&ctr->trace_head, 0, sizeof(unsigned int), st));
             if (tm) { int e = tm->begin(FAM_CLOSEST); if (e) return e; }
-            if (count) CRAY_LAUNCH_TRACE(false, true, d, c->ps, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
-            else if (fast) hipLaunchKernelGGL((k_trace32<kTraceClosest>), dim3(g_trace32), dim3(kBlock), 0, st, d, c->ps, q, nq, n_paths, (const uint32_t*)nullptr, (const unsigned int*)nullptr, ctr, &ctr->trace_head, b == 0 ? c->refill_min_b0 : c->refill_min, b == 0 ? 1u : 0u);
-            else CRAY_LAUNCH_TRACE(false, false, d, c->ps, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, b == 0 ? c->refill_min_b0 : c->refill_min);
+            if (count) CRAY_LAUNCH_TRACE(false, true, d, ps_b, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
+            else if (fast) hipLaunchKernelGGL((k_trace32<kTraceClosest>), dim3(g_trace32), dim3(kBlock), 0, st, d, ps_b, q, nq, n_paths, (const uint32_t*)nullptr, (const unsigned int*)nullptr, ctr, &ctr->trace_head, b == 0 ? c->refill_min_b0 : c->refill_min, b == 0 ? 1u : 0u);
+            else CRAY_LAUNCH_TRACE(false, false, d, ps_b, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, b == 0 ? c->refill_min_b0 : c->refill_min);
             if (tm) { int e = tm->end(); if (e) return e; }
         }
 
@@ -1016,26 +1060,33 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
         HIP_TRY(hipMemsetAsync(&ctr->n_shadow, 0, sizeof(unsigned int), st));
         HIP_TRY(hipMemsetAsync(&ctr->trace_head, 0, sizeof(unsigned int), st));
         if (tm) { int e = tm->begin(FAM_SHADE); if (e) return e; }
-        ShadeLaunch<0>::go(s->shade_variant, mode, d.shade_tables_bytes != 0, dim3(g_shade), st, d, c->ps, q, nq, n_paths, b, spp_pass, pp.s_lo, q_next, n_next,
+        ShadeLaunch<0>::go(s->shade_variant, mode, d.shade_tables_bytes != 0, dim3(g_shade), st, d, ps_b, ps_n, q, nq, n_paths, b, spp_pass, pp.s_lo, q_next, n_next,
                            c->shadow_queue, &ctr->n_shadow, ctr, trace_all, uni_nx, uni_ny, (const uint32_t*)c->pix_list, pp.px0, prm.seed);
         if (tm) { int e = tm->end(); if (e) return e; }
 
         if (mixed && b + 1 < d.max_depth) {
             if (tm) { int e = tm->begin(FAM_MIXED); if (e) return e; }
-            if (fast) hipLaunchKernelGGL((k_trace32<kTraceMixed>), dim3(g_trace32), dim3(kBlock), 0, st, d, c->ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, 0u,
+            if (fast) hipLaunchKernelGGL((k_trace32<kTraceMixed>), dim3(g_trace32), dim3(kBlock), 0, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, 0u,
                                          (const uint32_t*)q_next, (const unsigned int*)n_next, ctr, &ctr->trace_head, c->refill_min, 0u);
-            else if (hyb) hipLaunchKernelGGL(k_trace_mixed<true>, dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow,
+            else if (hyb) hipLaunchKernelGGL(k_trace_mixed<true>, dim3(g_trace), dim3(kBlock), 0, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow,
                                (const uint32_t*)q_next, (const unsigned int*)n_next, ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16));
-            else hipLaunchKernelGGL(k_trace_mixed<false>, dim3(g_trace), dim3(kBlock), 0, st, d, c->ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow,
+            else hipLaunchKernelGGL(k_trace_mixed<false>, dim3(g_trace), dim3(kBlock), 0, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow,
                                (const uint32_t*)q_next, (const unsigned int*)n_next, ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16));
             if (tm) { int e = tm->end(); if (e) return e; }
         } else {
             if (tm) { int e = tm->begin(FAM_ANY); if (e) return e; }
-            if (count) CRAY_LAUNCH_TRACE(true, true, d, c->ps, c->shadow_queue, &ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
-            else if (fast) hipLaunchKernelGGL((k_trace32<kTraceAny>), dim3(g_trace32), dim3(kBlock), 0, st, d, c->ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, 0u,
+            if (count) CRAY_LAUNCH_TRACE(true, true, d, ps_n, c->shadow_queue, &ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
+            else if (fast) hipLaunchKernelGGL((k_trace32<kTraceAny>), dim3(g_trace32), dim3(kBlock), 0, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, 0u,
                                               (const uint32_t*)nullptr, (const unsigned int*)nullptr, ctr, &ctr->trace_head, c->refill_min, 0u);
-            else CRAY_LAUNCH_TRACE(true, false, d, c->ps, c->shadow_queue, &ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min_any);
+            else CRAY_LAUNCH_TRACE(true, false, d, ps_n, c->shadow_queue, &ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min_any);
             if (tm) { int e = tm->end(); if (e) return e; }
+        }
+        if (c->log_queues) {   // diagnostics only: a host round trip per bounce
+            unsigned int nn = 0, ns = 0;
+            HIP_TRY(hipMemcpyAsync(&nn, n_next, sizeof(nn), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(&ns, &ctr->n_shadow, sizeof(ns), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            fprintf(stderr, "[cray] bounce %u: %u paths continue, %u shadow rays traced (pass of %u paths)\n", b, nn, ns, n_paths);
         }
     }
     if (tm) { int e = tm->begin(FAM_OTHER); if (e) return e; }
@@ -1158,13 +1209,13 @@ int render_local(cray_ctx* c, cray_scene* s, const cray_render_params* prm, cray
     // Paths in flight per pass.  Fewer, larger passes are faster (every launch of a pass ends in a drain phase, and late bounces
     // fill the chip better with more paths): configs[2] 295 ms at 32 Mi paths, 278 at 64 Mi, 267 with the whole frame (132.7 M
     // paths, 31 GB of state) in one pass; configs[3] 1 468 -> 1 340 ms.  HBM is there to be used: by default the pool may take
-    // up to 45 % of the memory that is free (or already held by this pool), 232 B per path.
+    // up to 72 % of the memory that is free (or already held by this pool), 364 B per path (two live buffers since round 3:
+    // configs[3]'s 531 M paths still fit one pass).
     size_t capacity = (size_t)prm->max_paths_in_flight;
     if (!capacity) {
         size_t free_b = 0, total_b = 0;
-        constexpr size_t kBytesPerPath = 26 * 8 + 6 * 4;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
-        capacity = (size_t)(0.45 * (double)(free_b + c->capacity * kBytesPerPath) / (double)kBytesPerPath);
+        capacity = (size_t)(0.72 * (double)(free_b + c->capacity * kBytesPerPath) / (double)kBytesPerPath);
         if (capacity < ((size_t)32 << 20)) capacity = (size_t)32 << 20;
     }
     const size_t need = n_pix_rank * (s_end > s_begin ? s_end - s_begin : 0);
@@ -1333,6 +1384,9 @@ extern "C" int cray_trace(cray_ctx* c, cray_scene* s, const cray_ray* rays, size
         HIP_TRY(hipMemcpy(ps.cb, col.data(), n * 8, hipMemcpyHostToDevice));
         for (size_t i = 0; i < n; i++) col[i] = 1.0;
         HIP_TRY(hipMemcpy(ps.cr, col.data(), n * 8, hipMemcpyHostToDevice));
+        std::vector<uint32_t> iota0(n);   // shadow slot i belongs to "path" i
+        for (size_t i = 0; i < n; i++) iota0[i] = (uint32_t)i;
+        HIP_TRY(hipMemcpy(ps.sp0, iota0.data(), n * 4, hipMemcpyHostToDevice));
     }
     const int g = grid_for(c, n, 8);
     Counters* ctr = c->counters;

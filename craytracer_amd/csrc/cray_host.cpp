@@ -643,7 +643,12 @@ extern "C" uint64_t cray_host_child_key_mismatches(const double* lo, const doubl
         const vec3 ov = mk(oo[0], oo[1], oo[2]), dv = mk(dd[0], dd[1], dd[2]);
         const vec3 rd = mk(1.0 / dd[0], 1.0 / dd[1], 1.0 / dd[2]);
         const double a = child_key(l, h, ov, dv), b = child_key_fast(l, h, ov, dv, rd);
-        if (memcmp(&a, &b, 8) != 0) bad++;
+        const double code = child_key_code(l, h, ov, dv, rd), cc = canonical_key(code);   // what the kernels compute: same decisions
+        if (memcmp(&a, &b, 8) != 0 || memcmp(&a, &cc, 8) != 0) { bad++; continue; }
+        // ... and the comparison the traversal makes agrees for every positive ray.tmax, the candidates themselves included
+        const double ts[6] = {kEps, 2.0 * kEps, a, nextafter(a, inf64()), 1.0, inf64()};
+        for (double t : ts)
+            if (t > 0.0 && ((a < t) != (code < t))) { bad++; break; }
     }
     if (n_checked) *n_checked = checked;
     return bad;

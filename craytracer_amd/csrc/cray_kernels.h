@@ -45,6 +45,13 @@ constexpr int kBlock = 256;
 //  (the shadow rays add to L, the segments write hit records), and together they have one drain phase instead
 //  of two — the lanes of a draining any-hit launch were 84 % idle for a fifth of its iterations.
 enum { kTraceClosest = 0, kTraceAny = 1, kTraceMixed = 2 };
+// the slab summary of a child box the timed and the counting kernels use (cray_math.h): encoded special values by default,
+// -DCRAY_KEY_PLAIN=1 for the +-inf form (A/B builds)
+#ifdef CRAY_KEY_PLAIN
+#define CRAY_CHILD_KEY child_key_fast
+#else
+#define CRAY_CHILD_KEY child_key_code
+#endif
 //  HYB        : certified f32 culling (cray_math.h hyb_key): interior nodes are read as 64-B f32 records, every decision the f32
 //               enclosure cannot certify is retaken from the f64 record in a RESOLVE step of the lane.  Same hits, same counters.
 template <int MODE, bool COUNT, bool HYB>
@@ -131,9 +138,10 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
         // run once with many lanes instead of in almost every iteration with one or two.
         if ((do_refill || idle == ~0ull) && pending) {
             if (CRAY_ANY_LANE) {
-                ps.lr[p] = ps.lr[p] + ps.cr[p];
-                ps.lg[p] = ps.lg[p] + ps.cg[p];
-                ps.lb[p] = ps.lb[p] + ps.cb[p];
+                const uint32_t l = ps.sp0[p];   // p is a shadow slot; L lives per original path
+                ps.lr[l] = ps.lr[l] + ps.cr[p];
+                ps.lg[l] = ps.lg[l] + ps.cg[p];
+                ps.lb[l] = ps.lb[l] + ps.cb[p];
             } else {
                 ps.ht[p] = hit_t; ps.hu[p] = hit_u; ps.hv[p] = hit_v; ps.hprim[p] = hit_prim;
             }
@@ -188,7 +196,7 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
                     resolve = false;
                 }
                 if (COUNT) n_nodes += 1;
-                const double k_root = fast_div ? child_key_fast(sc.root_lo, sc.root_hi, ray.o, ray.d, rd)
+                const double k_root = fast_div ? CRAY_CHILD_KEY(sc.root_lo, sc.root_hi, ray.o, ray.d, rd)
                                                : child_key(sc.root_lo, sc.root_hi, ray.o, ray.d);
                 if (k_root < ray.tmax) {
                     cur = sc.root_ref;
@@ -297,7 +305,7 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
             const uint32_t ref0 = (uint32_t)refs, ref1 = (uint32_t)(refs >> 32);
             const uint32_t axis = (uint32_t)(unsigned long long)__double_as_longlong(r6.y);
             double k0, k1;
-            if (fast_div) { k0 = child_key_fast(lo0, hi0, ray.o, ray.d, rd); k1 = child_key_fast(lo1, hi1, ray.o, ray.d, rd); }
+            if (fast_div) { k0 = CRAY_CHILD_KEY(lo0, hi0, ray.o, ray.d, rd); k1 = CRAY_CHILD_KEY(lo1, hi1, ray.o, ray.d, rd); }
             else { k0 = child_key(lo0, hi0, ray.o, ray.d); k1 = child_key(lo1, hi1, ray.o, ray.d); }
             // bvh.rs:92-98: dir[axis] < 0 -> push left, push right => right is visited first
             const bool right_first = ((dneg >> axis) & 1u) != 0;
@@ -482,9 +490,10 @@ __device__ __forceinline__ void trace_body32(const DevScene& sc, const PathState
         const bool do_refill = (unsigned int)__popcll(idle) >= refill_min && !exhausted;
         if ((do_refill || idle == ~0ull) && pending) {
             if (CRAY_ANY_LANE) {
-                ps.lr[p] = ps.lr[p] + ps.cr[p];
-                ps.lg[p] = ps.lg[p] + ps.cg[p];
-                ps.lb[p] = ps.lb[p] + ps.cb[p];
+                const uint32_t l = ps.sp0[p];   // p is a shadow slot; L lives per original path
+                ps.lr[l] = ps.lr[l] + ps.cr[p];
+                ps.lg[l] = ps.lg[l] + ps.cg[p];
+                ps.lb[l] = ps.lb[l] + ps.cb[p];
             } else {
                 ps.ht[p] = hit_t; ps.hu[p] = hit_u; ps.hv[p] = hit_v; ps.hprim[p] = hit_prim;
             }
@@ -521,7 +530,7 @@ __device__ __forceinline__ void trace_body32(const DevScene& sc, const PathState
                     ray.d = mk(ps.dx[p], ps.dy[p], ps.dz[p]);
                     ray.tmax = inf64();
                 }
-                skip = first_bounce ? -1 : ps.hprim[p];     // shadow rays and continued segments start on the last hit
+                skip = first_bounce ? -1 : (CRAY_ANY_LANE ? ps.sprim[p] : ps.hprim[p]);   // shadow rays and continued segments start on the last hit
                 o[0] = (float)ray.o.x; o[1] = (float)ray.o.y; o[2] = (float)ray.o.z;
                 d[0] = (float)ray.d.x; d[1] = (float)ray.d.y; d[2] = (float)ray.d.z;
                 rd[0] = 1.0f / d[0]; rd[1] = 1.0f / d[1]; rd[2] = 1.0f / d[2];
@@ -718,16 +727,16 @@ __global__ void __launch_bounds__(kBlock) k_raygen(DevScene sc, PathState ps, co
     }
 }
 
-// wave-aggregated append: one atomic per wave (ballot + popcount + lane prefix)
-__device__ __forceinline__ void queue_push(uint32_t* __restrict__ q, unsigned int* __restrict__ count, bool pred, uint32_t value) {
-    const unsigned long long mask = __ballot(pred);
-    if (mask == 0) return;
+// Wave-aggregated reservation of one position per CALLING lane in a block-level counter (LDS): one atomic per wave
+// (ballot of the lanes that are here + popcount + lane prefix).  Called from divergent code by exactly the lanes that append.
+__device__ __forceinline__ uint32_t lds_reserve(unsigned int* count) {
+    const unsigned long long mask = __ballot(1);
     const unsigned int lane = __lane_id();
     const unsigned int leader = __ffsll((long long)mask) - 1;
     unsigned int base = 0;
     if (lane == leader) base = atomicAdd(count, (unsigned int)__popcll(mask));
     base = __shfl(base, leader);
-    if (pred) q[base + __popcll(mask & ((1ull << lane) - 1ull))] = value;
+    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
 // (A material sort — per-class queues filled by a counting sort before k_shade — was measured in round 1 and made k_shade
@@ -744,7 +753,7 @@ __device__ __forceinline__ void queue_push(uint32_t* __restrict__ q, unsigned in
 // alternatives and run on the all-features instantiation only.
 enum { kModeSimple = 1, kModeUniform = 2, kModeLdsTables = 4, kModeIndependent = 8 };
 template <uint32_t F, int MODE = 0>
-__global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
+__global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc, PathState ps, PathState po, const uint32_t* __restrict__ queue,
                                                   const unsigned int* __restrict__ n_ptr, uint32_t n_fixed, uint32_t bounce,
                                                   uint32_t spp_pass, uint32_t s_lo, uint32_t* __restrict__ next_queue,
                                                   unsigned int* next_count, uint32_t* __restrict__ shadow_queue,
@@ -752,11 +761,13 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
                                                   uint32_t uni_nx, uint32_t uni_ny, const uint32_t* __restrict__ pix_list, uint32_t px0, uint64_t seed) {
     constexpr bool kSimple = (MODE & kModeSimple) != 0, kUniform = (MODE & kModeUniform) != 0, kIndependent = (MODE & kModeIndependent) != 0;
     const uint32_t n = n_ptr ? *n_ptr : n_fixed;
-    // Queue appends are aggregated per block over a tile of kShadeTile paths: survivors are collected
-    // in LDS (wave ballot + one LDS atomic per wave) and flushed with ONE global atomic per queue and
-    // tile.  One atomic per wave on a single device-wide counter (~88 returning atomics/us per word,
-    // MI355X_MICROARCH.md "dequeue") was half of this kernel's time: 1 M atomics per 33 M-path launch.
-    __shared__ uint32_t l_shadow[kShadeTile], l_next[kShadeTile];
+    // `ps` is the state of this bounce (live slots named by `queue`, or the identity at bounce 0), `po` the view the survivors
+    // are written to: the OTHER live buffer, the shadow buffer and L (cray_device.h).  A block walks tiles of `tsz` queue
+    // positions; a survivor's new live slot is tile * tsz + its rank among the tile's survivors (one LDS atomic per wave), its
+    // shadow ray's slot likewise — so what a tile leaves behind is contiguous whatever the survival rate, the next
+    // kernels read whole lines again, and the queue entries of a tile are consecutive integers.  The queues themselves
+    // are appended with ONE global atomic per queue and tile (one atomic per wave on a device-wide counter, ~88 returning
+    // atomics/us per word, was half of this kernel's time in round 1).
     __shared__ unsigned int c_shadow, c_next, c_skip, c_hit, g_shadow, g_next;
     // The small shading tables (materials -> lobes -> textures, lights and their CDF) are walked by DEPENDENT loads: five to eight
     // round trips per path, each a trip to L2 for a wave that has only one other wave to hide behind (2 waves / SIMD).  When the
@@ -792,22 +803,28 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
         }
         __syncthreads();
     }
-    const uint32_t n_tiles = (n + kShadeTile - 1) / kShadeTile;
+    // tile size: kShadeTile for the big launches, smaller (down to one pass of the block) when the launch would otherwise
+    // leave blocks without a tile — the late bounces of a frame, every bounce of an eighth of a frame
+    uint32_t per_tile = n / (gridDim.x * kBlock * 2u);
+    per_tile = per_tile < 1u ? 1u : (per_tile > kShadeTile / kBlock ? kShadeTile / kBlock : per_tile);
+    const uint32_t tsz = per_tile * kBlock;
+    const uint32_t n_tiles = (n + tsz - 1) / tsz;
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
       if (threadIdx.x == 0) { c_shadow = 0; c_next = 0; c_skip = 0; c_hit = 0; }
       __syncthreads();
-      for (uint32_t k = 0; k < kShadeTile / kBlock; k++) {
-        const uint32_t i = tile * kShadeTile + k * kBlock + threadIdx.x;
-        bool want_shadow = false, want_next = false, skip_shadow = false, was_hit = false;
-        uint32_t p = 0;
+      const uint32_t tile_base = tile * tsz;
+      for (uint32_t k = 0; k < per_tile; k++) {
+        const uint32_t i = tile_base + k * kBlock + threadIdx.x;
+        bool skip_shadow = false, was_hit = false;
         if (i < n) {
-            p = queue ? queue[i] : i;
+            const uint32_t p = queue ? queue[i] : i;        // live slot of this bounce
+            const uint32_t p0 = queue ? ps.p0[p] : i;       // original path: L, the Sobol sample index, the pixel
             // L is read and written only by the paths that add emission in this bounce (a light was hit or the ray
             // escaped to an Infinite light); for all others the 48 B of traffic per path are skipped
             rgb L = mkc(0, 0, 0);
             bool L_loaded = false;
             auto add_L = [&](rgb term) {
-                if (!L_loaded) { L = mkc(ps.lr[p], ps.lg[p], ps.lb[p]); L_loaded = true; }
+                if (!L_loaded) { L = mkc(po.lr[p0], po.lg[p0], po.lb[p0]); L_loaded = true; }
                 L = L + term;
             };
             const int32_t hp = ps.hprim[p];
@@ -838,7 +855,7 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
                         add_L(beta * Le * w);
                     }
                 }
-                if (L_loaded) { ps.lr[p] = L.r; ps.lg[p] = L.g; ps.lb[p] = L.b; }
+                if (L_loaded) { po.lr[p0] = L.r; po.lg[p0] = L.g; po.lb[p0] = L.b; }
             } else {
                 was_hit = true;
                 const ray_t ray = mkray(mk(ps.ox[p], ps.oy[p], ps.oz[p]), mk(ps.dx[p], ps.dy[p], ps.dz[p]));
@@ -851,11 +868,11 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
                 const vec3 n_s = sp.normal, x = sp.location;
 
                 // PathSegmentSamples::from (path_integrator.rs:26-36): dims 4+8k .. 11+8k
-                const uint32_t sidx = s_lo + p % spp_pass;
+                const uint32_t sidx = s_lo + p0 % spp_pass;
                 const uint32_t h = ps.hash[p];
                 double sa[4], sb[4];
                 if (kIndependent) {  // IndependentSampler: draws 4 + 8 b .. (4 + 7 b .. for simple_integrator) of the pixel sample's generator
-                    const uint32_t pix = pix_list[px0 + p / spp_pass];
+                    const uint32_t pix = pix_list[px0 + p0 / spp_pass];
                     uint32_t key[8];
                     indep_key(indep_pixel_hash(seed, pix % sc.film_w, pix / sc.film_w, sidx), key);
                     double dr[8];
@@ -970,13 +987,15 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
                     // The reference queries Scene::intersects unconditionally (:141).  When the term it
                     // gates is exactly zero (pdf 0, black f, light behind the surface) the answer cannot
                     // change L (L + 0 == L), so the query is skipped unless traversal is being counted.
-                    want_shadow = queried && (trace_all_shadow || !black(contrib));
+                    const bool want_shadow = queried && (trace_all_shadow || !black(contrib));
                     skip_shadow = queried && !want_shadow;
                     if (want_shadow) {
-                        ps.sox[p] = x.x; ps.soy[p] = x.y; ps.soz[p] = x.z;
-                        ps.sdx[p] = w_i.x; ps.sdy[p] = w_i.y; ps.sdz[p] = w_i.z;
-                        ps.stmax[p] = s_tmax;
-                        ps.cr[p] = contrib.r; ps.cg[p] = contrib.g; ps.cb[p] = contrib.b;
+                        const uint32_t q = tile_base + lds_reserve(&c_shadow);   // shadow slot: contiguous per tile
+                        po.sox[q] = x.x; po.soy[q] = x.y; po.soz[q] = x.z;
+                        po.sdx[q] = w_i.x; po.sdy[q] = w_i.y; po.sdz[q] = w_i.z;
+                        po.stmax[q] = s_tmax;
+                        po.cr[q] = contrib.r; po.cg[q] = contrib.g; po.cb[q] = contrib.b;
+                        po.sp0[q] = p0; po.sprim[q] = hp;
                     }
                 }
 
@@ -1008,19 +1027,18 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
                     // the loop condition of the next iteration (:54)
                     go = (bounce + 1 < sc.max_depth) && !black(beta);
                 }
-                if (L_loaded) { ps.lr[p] = L.r; ps.lg[p] = L.g; ps.lb[p] = L.b; }
+                if (L_loaded) { po.lr[p0] = L.r; po.lg[p0] = L.g; po.lb[p0] = L.b; }
                 if (go) {
-                    ps.ox[p] = x.x; ps.oy[p] = x.y; ps.oz[p] = x.z;  // Ray::new(location, w_i): no offset
-                    ps.dx[p] = ls.w_i.x; ps.dy[p] = ls.w_i.y; ps.dz[p] = ls.w_i.z;
-                    ps.br[p] = beta.r; ps.bg[p] = beta.g; ps.bb[p] = beta.b;
-                    ps.prev_pdf[p] = bsdf_pdf;
-                    ps.flags[p] = ls.specular ? 1u : 0u;
-                    want_next = true;
+                    const uint32_t q = tile_base + lds_reserve(&c_next);   // live slot of the next bounce: contiguous per tile
+                    po.ox[q] = x.x; po.oy[q] = x.y; po.oz[q] = x.z;  // Ray::new(location, w_i): no offset
+                    po.dx[q] = ls.w_i.x; po.dy[q] = ls.w_i.y; po.dz[q] = ls.w_i.z;
+                    po.br[q] = beta.r; po.bg[q] = beta.g; po.bb[q] = beta.b;
+                    po.prev_pdf[q] = bsdf_pdf;
+                    po.flags[q] = ls.specular ? 1u : 0u;
+                    po.hash[q] = h; po.p0[q] = p0; po.hprim[q] = hp;
                 }
             }
         }
-        queue_push(l_shadow, &c_shadow, want_shadow, p);
-        queue_push(l_next, &c_next, want_next, p);
         {
             const unsigned long long sk = __ballot(skip_shadow);
             if (sk != 0 && __lane_id() == (unsigned int)(__ffsll((long long)sk) - 1)) atomicAdd(&c_skip, (unsigned int)__popcll(sk));
@@ -1036,8 +1054,8 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
           if (c_hit) atomicAdd(&ctr->closest_hits, (unsigned long long)c_hit);
       }
       __syncthreads();
-      for (uint32_t j = threadIdx.x; j < c_shadow; j += kBlock) shadow_queue[g_shadow + j] = l_shadow[j];
-      for (uint32_t j = threadIdx.x; j < c_next; j += kBlock) next_queue[g_next + j] = l_next[j];
+      for (uint32_t j = threadIdx.x; j < c_shadow; j += kBlock) shadow_queue[g_shadow + j] = tile_base + j;
+      for (uint32_t j = threadIdx.x; j < c_next; j += kBlock) next_queue[g_next + j] = tile_base + j;
       __syncthreads();
     }
 }

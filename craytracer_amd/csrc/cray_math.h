@@ -232,6 +232,34 @@ CRAY_HD double child_key_fast(const double* __restrict__ lo, const double* __res
     return inside ? -inf64() : key;
 }
 
+// child_key_fast with the two special values ENCODED instead of materialised (round 3): the traversal only ever asks
+// `key < ray.tmax` (now, or when the far child is popped), with ray.tmax > 0.  So "contains(origin)" may be ANY value below
+// every ray.tmax and "rejected" ANY value for which the comparison is false:
+//     contains(origin)  ->  high word 0xffe00000: -(2^1023 .. 2^1024), finite, below every ray.tmax > -1.7e308
+//     rejected          ->  high word 0x7ff80000: a NaN, `key < x` is false for every x
+// which takes one 32-bit select each instead of a 64-bit select against +-inf (13 -> 9 VALU instructions per child box).
+// canonical_key() maps a code back to child_key's value; cray_host_child_key_mismatches holds the two together.
+CRAY_HD double child_key_code(const double* __restrict__ lo, const double* __restrict__ hi, vec3 o, vec3 d, vec3 rd) {
+    const double ax0 = div_fast(lo[0] - o.x, d.x, rd.x), bx0 = div_fast(hi[0] - o.x, d.x, rd.x);
+    const double ax1 = div_fast(lo[1] - o.y, d.y, rd.y), bx1 = div_fast(hi[1] - o.y, d.y, rd.y);
+    const double ax2 = div_fast(lo[2] - o.z, d.z, rd.z), bx2 = div_fast(hi[2] - o.z, d.z, rd.z);
+    const double tmin = fmax(fmax(fmin(ax0, bx0), fmin(ax1, bx1)), fmin(ax2, bx2));
+    const double tmax = fmin(fmin(fmax(ax0, bx0), fmax(ax1, bx1)), fmax(ax2, bx2));
+    const bool inside = tmin <= 0.0 && tmax >= 0.0;
+    const bool reject = tmin > tmax || !(tmax > kEps);
+    const double k2 = tmin > kEps ? tmin : tmax;
+    unsigned long long bits;
+    __builtin_memcpy(&bits, &k2, 8);
+    uint32_t hi32 = (uint32_t)(bits >> 32);
+    hi32 = reject ? 0x7ff80000u : hi32;
+    hi32 = inside ? 0xffe00000u : hi32;
+    bits = ((unsigned long long)hi32 << 32) | (bits & 0xffffffffull);
+    double out;
+    __builtin_memcpy(&out, &bits, 8);
+    return out;
+}
+CRAY_HD double canonical_key(double code) { return code != code ? inf64() : (code < -0x1p1022 ? -inf64() : code); }
+
 
 // ---------------------------------------------------------------------------------
 // Certified f32 culling ("hybrid" records).

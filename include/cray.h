@@ -279,6 +279,12 @@ int cray_film_pack(cray_ctx* ctx, uint32_t width, uint32_t height, uint32_t tile
 int cray_film_unpack(cray_ctx* ctx, uint32_t width, uint32_t height, uint32_t tile_width, uint32_t tile_height,
                      uint32_t world_size, const float* gathered, float* out);
 
+/* The shard map on its own (host only, no context, no GPU): the linear pixel indices y*W + x of the tiles `rank` owns, tile by
+ * tile (tiles numbered like generate_tiles, craytracer.rs:22-43; tile_index % world_size == rank), row-major inside a tile —
+ * the order of cray_film_pack's output and of the buffer cray_render_gather sends.  out may be NULL to query *n_pixels. */
+int cray_tile_pixels(uint32_t width, uint32_t height, uint32_t tile_width, uint32_t tile_height, uint32_t rank, uint32_t world_size,
+                     uint32_t* out, uint64_t capacity, uint64_t* n_pixels);
+
 /* Measurement aid for bench.py: GB/s of a plain 16-B-per-lane streaming read of `bytes` of HBM on this GPU (HIP events,
  * `repeats` launches after one warm-up) — the denominator "what a read-only kernel gets on this very box". */
 int cray_measure_stream_read(cray_ctx* ctx, uint64_t bytes, int repeats, double* gb_per_s);

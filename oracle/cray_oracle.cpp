@@ -1484,9 +1484,13 @@ static Scene* scene_create(const cray_scene_desc* d, int split_method) {
 /* render, src/bin/craytracer.rs:224-319 with generate_tiles :22-43, render_tile :164-206.
  * Deterministic variant: per pixel the sample batches are added in ascending
  * order (the reference's thread completion order is unspecified). */
+/* Edge of the square pixel tiles one job covers: 64 like the reference (craytracer.rs:232-233).  The film does not depend on it
+ * (per pixel the batches are accumulated in ascending order either way); bench.py's CPU baseline lowers it so that a bounded
+ * sample of the frame still gives every host thread many jobs (the reference gets them from tiles x sample batches). */
+static uint32_t g_tile = 64;
 static void render(const Scene& sc, uint64_t seed, int n_threads, uint32_t s_begin, uint32_t s_end, float* out,
                    Stats* total, double* seconds) {
-    const uint32_t W = sc.W, H = sc.H, TILE = 64, BATCH = 8;
+    const uint32_t W = sc.W, H = sc.H, TILE = g_tile, BATCH = 8;
     std::vector<float> pixels((size_t)W * H * 3, 0.0f);
     uint32_t tiles_x = (W + TILE - 1) / TILE, tiles_y = (H + TILE - 1) / TILE;
     std::atomic<uint32_t> next(0);
@@ -1659,6 +1663,8 @@ void orc_camera_ray(void* s, uint64_t seed, uint32_t x, uint32_t y, uint32_t sam
     ray7[0] = r.o.x; ray7[1] = r.o.y; ray7[2] = r.o.z; ray7[3] = r.d.x; ray7[4] = r.d.y; ray7[5] = r.d.z; ray7[6] = r.tmax;
 }
 
+/* job granularity of orc_render (pixels per tile edge; 0 restores the reference's 64) */
+void orc_set_tile(uint32_t tile) { g_tile = tile ? tile : 64; }
 /* 0: correctly rounded sin/cos in the sampling functions (default); 1: platform libm */
 void orc_set_libm_mode(int mode) { g_libm_mode = mode; }
 /* the first n draws of IndependentSampler for pixel sample (seed, x, y, sample_index) */

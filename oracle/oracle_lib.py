@@ -100,6 +100,12 @@ def lib():
     return _lib
 
 
+def set_tile(tile):
+    """Pixels per edge of the square tile one job of OracleScene.render covers (default 64, the reference's; 0 restores it).
+    The film does not depend on it; bench.py's CPU baseline uses small tiles so that a bounded sample keeps every thread busy."""
+    lib().orc_set_tile(int(tile))
+
+
 def set_libm_mode(mode):
     """0: correctly rounded sin/cos in the sampling functions (default); 1: platform libm."""
     lib().orc_set_libm_mode(mode)

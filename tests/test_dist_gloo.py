@@ -1,4 +1,10 @@
-"""N>1 path on CPU: world_size-2 gloo run of the tile shard + Film-tile gather."""
+"""The N > 1 shard on CPU: a world-size-2 gloo run of the tile map the PRODUCT uses (cray_tile_pixels, the C ABI's own map —
+the one cray_film_pack packs with and cray_render_gather sends with), gloo standing in for the RCCL transport.
+
+Replaces the merge of the reference's worker threads into one `Mutex<Vec<f32>>` (src/bin/craytracer.rs:245, 271-291,
+182-188): every rank holds the right values on its own tiles only, packs them in the ABI's order, rank 0 receives each
+rank's block at its offset and un-permutes with the ABI's all-ranks map.  The assembled film must be the whole film.
+"""
 import os
 import socket
 
@@ -7,38 +13,63 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from craytracer_amd import backend
 from craytracer_amd import dist as cdist
 
 
-def test_rank_pixels_partition_the_film():
-    for (W, H) in [(1920, 1080), (100, 70), (64, 64), (65, 1)]:
+def test_the_abi_s_tile_map_is_the_reference_s():
+    """cray_tile_pixels against the independent Python restatement of generate_tiles (craytracer.rs:22-43)."""
+    for (W, H) in [(1920, 1080), (100, 70), (64, 64), (65, 1), (130, 67)]:
         for world in (1, 2, 3, 8):
-            allp = np.concatenate([cdist.rank_pixels(W, H, r, world) for r in range(world)])
-            assert len(allp) == W * H and len(np.unique(allp)) == W * H
-    # tile order of generate_tiles (craytracer.rs:32-33): ty outer, tx inner; 64x64 tiles
-    p = cdist.rank_pixels(130, 70, 1, 3)
-    assert p[0] == 64 and p[1] == 65          # tile 1 = (tx=64, ty=0)
+            parts = [backend.tile_pixels(W, H, r, world) for r in range(world)]
+            for r, p in enumerate(parts):
+                assert np.array_equal(p, cdist.rank_pixels(W, H, r, world)), (W, H, r, world)
+            allp = np.concatenate(parts)
+            assert len(allp) == W * H and len(np.unique(allp)) == W * H   # the shares partition the film
+    p = backend.tile_pixels(130, 70, 1, 3)
+    assert p[0] == 64 and p[1] == 65          # tile 1 = (tx = 64, ty = 0): ty outer, tx inner, 64x64 tiles
+    assert np.array_equal(backend.tile_pixels(130, 67, 1, 2, tile=(32, 16)), cdist.rank_pixels(130, 67, 1, 2, 32, 16))
+    for bad in ((0, 10, 0, 1), (10, 10, 2, 2), (10, 10, 0, 0)):
+        try:
+            backend.tile_pixels(*bad)
+            raise AssertionError('accepted %r' % (bad,))
+        except backend.CrayError:
+            pass
 
 
 def _worker(rank, world, port, W, H, out_path):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    # a fake per-rank film: the right values on this rank's tiles, garbage elsewhere
+    # a per-rank film as a GPU of the shard would hold it: the right values on this rank's tiles, garbage elsewhere
     truth = torch.arange(W * H * 3, dtype=torch.float32).reshape(H, W, 3) * 0.25
     local = torch.full((H, W, 3), -7.0)
-    mine = torch.from_numpy(cdist.rank_pixels(W, H, rank, world))
+    mine = torch.from_numpy(backend.tile_pixels(W, H, rank, world).astype(np.int64))
     local.reshape(-1, 3)[mine] = truth.reshape(-1, 3)[mine]
-    out = cdist.gather_film(local, W, H, rank, world)
+    packed = local.reshape(-1, 3)[mine].contiguous()                 # cray_film_pack's order
+    counts = [len(backend.tile_pixels(W, H, r, world)) for r in range(world)]
     if rank == 0:
-        assert torch.equal(out, truth)
+        # grouped receive of exactly each rank's pixel count at its offset (gather_tiles in cray_hip.hip), then the un-permute
+        gathered = torch.empty((W * H, 3), dtype=torch.float32)
+        gathered[: counts[0]] = packed
+        off = counts[0]
+        for r in range(1, world):
+            buf = torch.empty((counts[r], 3), dtype=torch.float32)
+            dist.recv(buf, src=r)
+            gathered[off: off + counts[r]] = buf
+            off += counts[r]
+        all_pix = torch.from_numpy(np.concatenate([backend.tile_pixels(W, H, r, world) for r in range(world)]).astype(np.int64))
+        out = torch.empty((W * H, 3), dtype=torch.float32)
+        out[all_pix] = gathered                                      # k_unpack_tiles
+        assert torch.equal(out.reshape(H, W, 3), truth)
         open(out_path, 'w').write('ok')
     else:
-        assert out is None
+        dist.send(packed, dst=0)
+    dist.barrier()
     dist.destroy_process_group()
 
 
-def test_gather_film_world2_gloo(tmp_path):
+def test_shard_and_gather_world2_gloo(tmp_path):
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]

@@ -3,11 +3,13 @@ tests/test_gpu_fullsize.py, configs[0] the CPU-only plumbing case of tests/test_
 
   configs[1]  cornell 512x512, 64 spp, depth 8: the WHOLE 64-spp frame is pixel-exact (the oracle renders it in seconds).
   configs[3]  staircase-class 1920x1080, 256 spp, depth 12 (1.03 M triangles, 10 textures up to 3500x2625): one whole
-              sample pixel-exact with equal traversal counters, random paths of sample indices up to 255 bit-exact.
+              sample pixel-exact with equal traversal counters, random paths of sample indices up to 255 bit-exact, ten whole
+              pixels of the 256-spp frame (32 batches, film accumulation included) bit-exact.
   configs[4]  dragon-class 3840x2160, 1024 spp (the 8-GPU case): Sobol sample indices >= 64 (src/sampling.rs:223-246),
               the `/ 1024` resolve, the 8.3 M-pixel film and the ragged world_size = 8 tiling of a 60 x 34-tile film
               (src/bin/craytracer.rs:22-43) — one whole sample pixel-exact with equal counters, >= 200 random
-              (x, y, s) paths bit-exact, the eight rank shares add up to the unsharded film.
+              (x, y, s) paths bit-exact, the eight rank shares add up to the unsharded film, six whole pixels of the whole
+              1024-spp frame (128 batches) bit-exact.
 """
 import numpy as np
 import pytest
@@ -76,6 +78,34 @@ def test_config3_staircase_random_paths_of_late_samples(staircase_full):
             assert np.array_equal(L[y, x, j], orc.render_pixel(x, y, s0 + j, seed=0)), (x, y, s0 + j)
 
 
+def _reference_pixel(orc, x, y, spp, batch=8):
+    """One film pixel the way the reference accumulates it: per batch of 8 samples an f64 sum in sample order, cast to f32
+    and added into the f32 film (render_tile, craytracer.rs:175-188), batches ascending; `/ num_samples` in f32 (:253-259)."""
+    acc = np.zeros(3, dtype=np.float32)
+    for b0 in range(0, spp, batch):
+        c = np.zeros(3, dtype=np.float64)
+        for s in range(b0, min(b0 + batch, spp)):
+            c = c + orc.render_pixel(x, y, s, seed=0)
+        acc = acc + c.astype(np.float32)
+    return acc / np.float32(spp)
+
+
+def test_config3_whole_pixels_through_all_256_samples(staircase_full):
+    """configs[3], film accumulation included: ten whole pixels of the 1920x1080x256-spp frame — 32 batches each — equal the
+    oracle's per-path radiances summed the reference's way, bit for bit."""
+    sc, dev, orc = staircase_full
+    film, st = dev.render(seed=0)
+    assert st['paths'] == 1920 * 1080 * 256 and st['nonfinite'] == 0
+    rng = np.random.default_rng(256)
+    pixels = [(960, 540), (400, 800)] + [(int(rng.integers(0, 1920)), int(rng.integers(0, 1080))) for _ in range(8)]
+    lit = 0
+    for x, y in pixels:
+        expect = _reference_pixel(orc, x, y, 256)
+        assert np.array_equal(film[y, x], expect), (x, y, film[y, x], expect)
+        lit += int(expect.max() > 0)
+    assert lit >= 6     # the check is about pixels that received light
+
+
 @pytest.fixture(scope='module')
 def dragon_4k(ctx):
     sc = scenes.dragon(3840, 2160, 1024, 8)    # configs[4]: 7.2 M triangles, 8.3 M pixels, 1024 spp
@@ -99,6 +129,20 @@ def test_config4_random_paths_with_sobol_indices_beyond_64(dragon_4k):
             checked += 1
         del L
     assert checked >= 200
+
+
+def test_config4_whole_pixels_through_all_1024_samples(dragon_4k):
+    """configs[4], film accumulation included: the WHOLE 3840x2160x1024-spp frame is rendered (8.5 G paths, 128 batches per
+    pixel) and six of its pixels equal the oracle's 1024 per-path radiances summed the reference's way, `/ 1024` included."""
+    sc, dev, orc = dragon_4k
+    film, st = dev.render(seed=0)
+    assert st['paths'] == 3840 * 2160 * 1024 and st['nonfinite'] == 0 and st['stack_overflow'] == 0
+    rng = np.random.default_rng(1024)
+    pixels = [(1920, 1080), (2000, 1240)] + [(int(rng.integers(0, 3840)), int(rng.integers(0, 2160))) for _ in range(4)]
+    for x, y in pixels:
+        expect = _reference_pixel(orc, x, y, 1024)
+        assert np.array_equal(film[y, x], expect), (x, y, film[y, x], expect)
+    del film
 
 
 def test_config4_one_whole_late_sample_is_pixel_exact(dragon_4k):

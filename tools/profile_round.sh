@@ -2,9 +2,11 @@
 # tools/profile_round.sh <tag> [workload]: the rocprofv3 evidence of a round, on the GPU box.
 #   1. --kernel-trace --stats over the default bench command (3 timed frames): per-kernel average duration
 #   2. --pmc FETCH_SIZE and --pmc WRITE_SIZE, each in its OWN pass (TCC slots: 3 + 2 of 4) over one frame: HBM traffic
-#   3. --pmc SQ pass (lane utilisation, waits) and a TCC hit-rate pass over one frame
+#   3. --pmc SQ pass (lane utilisation, waits), a TCC hit-rate pass and a TA pass over one frame
 # Counter passes never carry trace options other than the implicit kernel dispatch records (gpurun refuses mixes).
-# Results: gpurun_out/prof_<tag>/{kernel_stats.csv,pmc_*.csv,bench.log}; copy what should be judged into profiles/.
+# Results: gpurun_out/prof_<tag>/{kernel_stats.csv,pmc_*.csv,bench.log,pmc_summary.json}.  Back in the build container:
+#   tools/adopt_profile.sh <tag> [workload]   copies them to profiles/<tag>/ and rewrites profiles/hbm_traffic.json,
+# keyed by the source hash of the library that was profiled (bench.py refuses the traffic figure for any other build).
 set -e
 tag=$1; wl=${2:-dragon}
 root=$(cd "$(dirname "$0")/.." && pwd)
@@ -22,4 +24,5 @@ for pass in "fetch_size:FETCH_SIZE" "write_size:WRITE_SIZE" "sq:SQ_WAVES SQ_INST
   rm -rf $out/pmc_$name
 done
 rm -rf $out/stats
+python3 tools/pmc_summary.py $out $out/pmc_summary.json > $out/pmc_summary.txt 2>&1 || true
 ls -la $out

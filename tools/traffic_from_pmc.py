@@ -5,7 +5,9 @@ HBM bytes = FETCH_SIZE[KB] * 1024 * 2: on gfx950 FETCH_SIZE counts 128-B request
 (MI355X_MICROARCH.md "HBM"); tools/calib_fetch.hip confirms the factor for THIS access pattern
 (random whole 128-B records, 16 B per lane per load: 1.707 GB reported for 3.322 GB read; a
 coalesced 16-B/lane stream: 1.611 GB reported for 3.221 GB read).  WRITE_SIZE is taken as is.
-usage: traffic_from_pmc.py <workload> <fetch counter_collection.csv> [<write counter_collection.csv> [<pmc_summary.json>]]
+usage: traffic_from_pmc.py <workload> <fetch counter_collection.csv> [<write counter_collection.csv> [<pmc_summary.json> [<bench.log>]]]
+The bench.log of the profiled run (its JSON line) names the source hash of the library that was profiled: bench.py only uses
+the traffic figure when that hash equals the hash of the library it runs.
 (the summary of tools/pmc_summary.py adds, per traversal / shading kernel, how busy the other units were: VALU issue, texture
 addresser, share of wave-cycles spent waiting)"""
 import json
@@ -64,6 +66,10 @@ if __name__ == '__main__':
         entry['units'] = {k: {f: v[f] for f in ('valu_issue_share_min', 'ta_busy', 'wait_any_share_of_wave_cycles', 'valu_lane_utilisation', 'tcc_hit_rate') if f in v}
                           for k, v in summ.items() if k.startswith('k_trace') or k.startswith('k_shade')}
         entry['units_source'] = os.path.relpath(sys.argv[4], root)
+    if len(sys.argv) > 5:
+        for line in open(sys.argv[5]):
+            if line.startswith('{'):
+                entry['source_hash'] = json.loads(line)['config']['build'].get('source_hash')
     data[workload] = entry
     json.dump(data, open(path, 'w'), indent=1)
     print(json.dumps(entry, indent=1))
