@@ -1087,6 +1087,12 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
             HIP_TRY(hipMemcpyAsync(&ns, &ctr->n_shadow, sizeof(ns), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             fprintf(stderr, "[cray] bounce %u: %u paths continue, %u shadow rays traced (pass of %u paths)\n", b, nn, ns, n_paths);
+            if (count) {   // running totals of the traversal counters (differences between lines = this bounce's queries)
+                Counters hc;
+                HIP_TRY(hipMemcpy(&hc, ctr, sizeof(hc), hipMemcpyDeviceToHost));
+                fprintf(stderr, "[cray]   so far: closest %llu rays %llu nodes %llu prims; shadow %llu rays %llu nodes %llu prims\n", hc.closest_rays, hc.closest_nodes,
+                        hc.closest_prims, hc.shadow_rays, hc.shadow_nodes, hc.shadow_prims);
+            }
         }
     }
     if (tm) { int e = tm->begin(FAM_OTHER); if (e) return e; }

@@ -207,5 +207,20 @@ int main() {
             }
         }
     }
+    // launch floor: the same chase with few steps and few blocks (what a nearly empty bounce of the traversal looks like):
+    // time = fixed cost of a launch that touches a 768 MB table + steps x (dependent fetch + work)
+    for (int g : {1024, 64}) {
+        for (uint32_t st : {25u, 50u, 100u, 200u, 400u}) {
+            float best = 1e9f;
+            for (int rep = 0; rep < 4; rep++) {
+                hipEventRecord(e0, 0);
+                hipLaunchKernelGGL(chase<0>, dim3(g), dim3(kBlock), 0, 0, table, n_rec, 32768u, 0u, st, 154, out, sink, last);
+                hipEventRecord(e1, 0); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                if (rep && ms < best) best = ms;
+            }
+            printf("floor: %4d blocks, %3u dependent steps: %.3f ms = %.2f us per step\n", g, st, best, best * 1e3 / st);
+        }
+    }
     return 0;
 }

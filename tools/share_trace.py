@@ -45,6 +45,7 @@ def main():
     ap.add_argument('--rank', type=int, default=0)
     ap.add_argument('--frames', type=int, default=3)
     ap.add_argument('--report', default='')
+    ap.add_argument('--count', type=int, default=0, help='count_traversal mode of the renders (with CRAY_LOG_QUEUES=1: per-bounce counters)')
     args = ap.parse_args()
     if args.report:
         return report(args.report)
@@ -57,7 +58,7 @@ def main():
     dev = ctx.upload(backend.HostScene(scene, resident=True))
     film = torch.zeros((H, W, 3), dtype=torch.float32, device='cuda')
     for _ in range(args.frames):
-        _, st = dev.render(seed=0, rank=args.rank, world_size=args.world, out_device_ptr=film.data_ptr())
+        _, st = dev.render(seed=0, rank=args.rank, world_size=args.world, out_device_ptr=film.data_ptr(), count_traversal=args.count)
         torch.cuda.synchronize()
     print({k: round(v, 2) if isinstance(v, float) else v for k, v in st.items() if k.endswith('_ms') or k in ('seconds', 'paths')}, file=sys.stderr)
 
