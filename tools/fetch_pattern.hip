@@ -28,10 +28,10 @@ __device__ __forceinline__ double work(double x, const double2* r, int n_ops) {
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true); }
 
-template <int MODE>
-__global__ void __launch_bounds__(kBlock, 4) chase(const double2* __restrict__ table, uint32_t n_rec, uint32_t hot_n, uint32_t hot, uint32_t steps, int n_ops, double* out,
+template <int MODE, int WAVES = 4>
+__global__ void __launch_bounds__(kBlock, WAVES) chase(const double2* __restrict__ table, uint32_t n_rec, uint32_t hot_n, uint32_t hot, uint32_t steps, int n_ops, double* out,
                                                    unsigned long long* sink, uint32_t* last_idx) {
-    __shared__ double2 stage[(kBlock / 64) * 64 * kRow];
+    __shared__ double2 stage[MODE == 1 ? (kBlock / 64) * 64 * kRow : 1];   // only mode B stages through LDS (37 KB would cap the other modes at 4 blocks per CU)
     const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     double2* st = stage + wave * 64 * kRow;
     uint32_t idx = (blockIdx.x * kBlock + threadIdx.x) * 2654435761u % n_rec;
@@ -179,7 +179,8 @@ int main() {
     }
     hipMemcpy(table, h.data(), (size_t)n_rec * 128, hipMemcpyHostToDevice);
     const int grid = 256 * 4;
-    uint32_t* last; hipMalloc(&last, (size_t)grid * kBlock * 4);
+    constexpr int kMaxGrid = 256 * 8;   // the occupancy rows launch up to 8 blocks per CU: every launch writes last[blockIdx.x * kBlock + threadIdx.x]
+    uint32_t* last; hipMalloc(&last, (size_t)kMaxGrid * kBlock * 4);
     std::vector<uint32_t> ref((size_t)grid * kBlock), got((size_t)grid * kBlock);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const uint32_t steps = 2000;
@@ -205,6 +206,24 @@ int main() {
                 if (rep == 1) printf("hot %u/8 ops/step %3d  mode %s  %.2f ms  %.2f G lane-steps/s\n", hot, n_ops, mode == 0 ? "A per-lane        " : mode == 1 ? "B cooperative+LDS " : mode == 2 ? "C quad + DPP      " : mode == 4 ? "E quad + cndmask_dpp" : "D per-lane 4 loads", ms,
                                      (double)grid * kBlock * steps / (ms * 1e-3) / 1e9);
             }
+        }
+    }
+    // occupancy: the per-lane fetch (mode A) with 2 / 4 / 8 waves per SIMD resident (grid = 256 CUs x waves blocks of 4 waves)
+    for (uint32_t hot : {0u, 3u}) {
+        for (int waves : {2, 4, 8}) {
+            float best = 1e9f;
+            const int g = 256 * waves;
+            if (g > kMaxGrid) { printf("grid too large\n"); return 1; }
+            const uint32_t st = 2000u * 4u / (uint32_t)waves;   // the same number of lane-steps in every row
+            for (int rep = 0; rep < 3; rep++) {
+                hipEventRecord(e0, 0);
+                if (waves == 8) hipLaunchKernelGGL((chase<0, 8>), dim3(g), dim3(kBlock), 0, 0, table, n_rec, 32768u, hot, st, 154, out, sink, last);
+                else hipLaunchKernelGGL((chase<0, 4>), dim3(g), dim3(kBlock), 0, 0, table, n_rec, 32768u, hot, st, 154, out, sink, last);
+                hipEventRecord(e1, 0); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                if (rep && ms < best) best = ms;
+            }
+            printf("occupancy: hot %u/8, %d waves per SIMD: %.2f ms  %.2f G lane-steps/s\n", hot, waves, best, (double)g * kBlock * st / (best * 1e-3) / 1e9);
         }
     }
     // launch floor: the same chase with few steps and few blocks (what a nearly empty bounce of the traversal looks like):
