@@ -265,7 +265,7 @@ def main():
             roofline['other_bounds'] = {'source': ent.get('units_source'), 'kernels': {
                 k: {'ta_busy_share': v.get('ta_busy'), 'valu_issue_share_min': v.get('valu_issue_share_min'),
                     'valu_lane_utilisation': v.get('valu_lane_utilisation'), 'wait_share_of_wave_cycles': v.get('wait_any_share_of_wave_cycles'),
-                    'l2_hit_rate': v.get('tcc_hit_rate')} for k, v in u.items()}}
+                    'l2_hit_rate': v.get('tcc_hit_rate'), 'l1_fill_bytes_per_clk_per_cu': v.get('l1_fill_bytes_per_clk_per_cu')} for k, v in u.items()}}
         # the second kernel of the frame: k_shade (path state + shading records)
         n_shaded = cst['closest_rays']                      # every traced segment is shaded once
         n_hit = cst.get('closest_hits', 0) or n_shaded      # segments that hit something

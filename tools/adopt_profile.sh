@@ -9,7 +9,7 @@ src=gpurun_out/prof_$tag
 dst=profiles/$tag
 mkdir -p $dst
 # the per-dispatch counter files are tens of MB with the BVH builder's thousands of launches: keep the k_* render kernels only
-for f in pmc_fetch_size pmc_write_size pmc_sq pmc_tcc pmc_ta; do
+for f in pmc_fetch_size pmc_write_size pmc_sq pmc_tcc pmc_ta pmc_tcp; do
   [ -f $src/$f.csv ] && python3 - "$src/$f.csv" "$dst/$f.csv" <<'PY'
 import sys, pandas as pd
 df = pd.read_csv(sys.argv[1])

@@ -16,7 +16,7 @@ mkdir -p $out
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o run -- python3 bench.py --workload $wl --steps 3 --warmup 1 --cpu-baseline 0 > $out/bench.log 2> $out/stats.log
 cp $(find $out/stats -name '*kernel_stats.csv' | head -1) $out/kernel_stats.csv
-for pass in "fetch_size:FETCH_SIZE" "write_size:WRITE_SIZE" "sq:SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU" "tcc:TCC_HIT_sum TCC_MISS_sum" "ta:TA_TA_BUSY_sum GRBM_GUI_ACTIVE"; do
+for pass in "fetch_size:FETCH_SIZE" "write_size:WRITE_SIZE" "sq:SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU" "tcc:TCC_HIT_sum TCC_MISS_sum" "ta:TA_TA_BUSY_sum GRBM_GUI_ACTIVE" "tcp:TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
   name=${pass%%:*}; ctrs=${pass#*:}
   rocprofv3 --pmc $ctrs --output-format csv -d $out/pmc_$name -o run -- python3 bench.py --workload $wl --steps 1 --warmup 0 --cpu-baseline 0 --count-pass 0 > $out/pmc_$name.bench.log 2> $out/pmc_$name.log || echo "pass $name failed" >> $out/failed.txt
   f=$(find $out/pmc_$name -name '*counter_collection.csv' | head -1)

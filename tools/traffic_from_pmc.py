@@ -63,7 +63,7 @@ if __name__ == '__main__':
     entry['shade_bytes_per_frame'] = round(sum((v.get('fetch_bytes_per_launch', 0) + v.get('write_bytes_per_launch', 0)) * v['launches'] for v in sh))
     if len(sys.argv) > 4:
         summ = json.load(open(sys.argv[4]))
-        entry['units'] = {k: {f: v[f] for f in ('valu_issue_share_min', 'ta_busy', 'wait_any_share_of_wave_cycles', 'valu_lane_utilisation', 'tcc_hit_rate') if f in v}
+        entry['units'] = {k: {f: v[f] for f in ('valu_issue_share_min', 'ta_busy', 'wait_any_share_of_wave_cycles', 'valu_lane_utilisation', 'tcc_hit_rate', 'l1_fill_bytes_per_clk_per_cu') if f in v}
                           for k, v in summ.items() if k.startswith('k_trace') or k.startswith('k_shade')}
         entry['units_source'] = os.path.relpath(sys.argv[4], root)
     if len(sys.argv) > 5:
