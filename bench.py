@@ -83,6 +83,32 @@ def exchange_comm_id(backend, rank, world):
     return cid, store
 
 
+def committed_traffic(workload, lib_hash, launches_per_frame, world=1, precision='f64', path=None):
+    """HBM bytes per traversal launch from the committed counter profile (profiles/hbm_traffic.json) — but only when that profile
+    is of the very build of the kernels this process runs: `lib_hash` is the source hash stamped on the loaded library, the
+    profile carries the hash of the library that was profiled (tools/profile_round.sh + tools/adopt_profile.sh).  Any other
+    build's counters are refused: traffic None, the reason in the provenance.  Returns (traffic, provenance, entry)."""
+    path = path or os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
+    ent = {}
+    if os.path.exists(path):
+        try:
+            ent = json.load(open(path)).get(workload, {})
+        except Exception:
+            ent = {}
+    if not ent or world != 1 or precision != 'f64':
+        return None, None, ent
+    provenance = {'file': 'profiles/hbm_traffic.json', 'pmc_csv': ent.get('source'), 'profiled_source_hash': (ent.get('source_hash') or '')[:16],
+                  'library_source_hash': lib_hash[:16], 'profiled_git': ent.get('git'),
+                  'method': 'FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 from separate rocprofv3 --pmc passes (tools/traffic_from_pmc.py)'}
+    if not ent.get('source_hash') or ent.get('source_hash') != lib_hash:
+        provenance['refused'] = 'the committed counters are of another build of the kernels: re-run tools/profile_round.sh'
+        return None, provenance, ent
+    # per launch of THIS run: the profiled frame's traversal traffic over this run's launches per frame (the pass plan, hence
+    # the number of launches, depends on the path pool; the bytes per frame do not)
+    per_frame = ent.get('trace_bytes_per_frame') or 0
+    return (round(per_frame / max(1.0, launches_per_frame)) if per_frame else None), provenance, ent
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -224,25 +250,7 @@ def main():
         # HBM bytes the PMC counters saw for these kernels.  Counters need their own rocprofv3 --pmc passes, so this run cannot
         # measure them: they come from the committed profile of THIS build (tools/profile_round.sh -> profiles/hbm_traffic.json),
         # and are refused when the profile is of another build (source hash of the kernels differs from the loaded library's).
-        traffic, provenance, ent = None, None, {}
-        tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
-        lib_hash = hip_build.loaded_hash()   # of the library this process runs (its stamp), not of whatever the tree holds now
-        if os.path.exists(tpath):
-            try:
-                ent = json.load(open(tpath)).get(args.workload, {})
-            except Exception:
-                ent = {}
-        if ent and world == 1 and args.precision == 'f64':
-            provenance = {'file': 'profiles/hbm_traffic.json', 'pmc_csv': ent.get('source'), 'profiled_source_hash': (ent.get('source_hash') or '')[:16],
-                          'library_source_hash': lib_hash[:16], 'profiled_git': ent.get('git'),
-                          'method': 'FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 from separate rocprofv3 --pmc passes (tools/traffic_from_pmc.py)'}
-            if ent.get('source_hash') == lib_hash:
-                # per launch of THIS run: the profiled frame's traversal traffic over this run's launches per frame (the pass
-                # plan, hence the number of launches, depends on the path pool; the bytes per frame do not)
-                per_frame = ent.get('trace_bytes_per_frame') or 0
-                traffic = round(per_frame / max(1.0, launches_per_frame)) if per_frame else None
-            else:
-                provenance['refused'] = 'the committed counters are of another build of the kernels: re-run tools/profile_round.sh'
+        traffic, provenance, ent = committed_traffic(args.workload, hip_build.loaded_hash(), launches_per_frame, world, args.precision)
         hbm_gbs = traffic / (avg_ms * 1e-3) / 1e9 if traffic and avg_ms > 0 else None
         roofline = {'bound': 'hbm',
                     'kernel': 'k_trace family (k_trace<closest> + k_trace_mixed + k_trace<any>)',

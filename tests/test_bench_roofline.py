@@ -1,0 +1,35 @@
+"""bench.py's `roofline.traffic` comes from a committed counter profile; it must be REFUSED unless that profile is of the very
+build of the kernels the process runs (round 2 reported the counters of another build next to HEAD's timings)."""
+import json
+
+import bench
+
+
+def test_traffic_is_refused_for_another_build(tmp_path):
+    p = tmp_path / 'hbm_traffic.json'
+    p.write_text(json.dumps({'dragon': {'source': 'profiles/x/pmc_fetch_size.csv', 'git': 'abc1234', 'source_hash': 'a' * 64,
+                                        'trace_bytes_per_frame': 900e9, 'shade_bytes_per_frame': 70e9}}))
+    t, prov, ent = bench.committed_traffic('dragon', 'a' * 64, 9.0, path=str(p))
+    assert t == 100e9 and 'refused' not in prov and prov['profiled_source_hash'] == 'a' * 16
+    t, prov, ent = bench.committed_traffic('dragon', 'b' * 64, 9.0, path=str(p))
+    assert t is None and 'refused' in prov and prov['library_source_hash'] == 'b' * 16
+    # a profile without a hash (the round-2 format) is never trusted; other workloads, N > 1 and the fast mode have no figure
+    p.write_text(json.dumps({'dragon': {'source': 'x', 'git': 'abc', 'trace_bytes_per_frame': 900e9}}))
+    t, prov, _ = bench.committed_traffic('dragon', 'a' * 64, 9.0, path=str(p))
+    assert t is None and 'refused' in prov
+    assert bench.committed_traffic('cornell', 'a' * 64, 9.0, path=str(p))[0] is None
+    p.write_text(json.dumps({'dragon': {'source_hash': 'a' * 64, 'trace_bytes_per_frame': 900e9}}))
+    assert bench.committed_traffic('dragon', 'a' * 64, 9.0, world=2, path=str(p))[0] is None
+    assert bench.committed_traffic('dragon', 'a' * 64, 9.0, precision='f32', path=str(p))[0] is None
+
+
+def test_the_committed_profile_is_of_the_committed_kernels():
+    """profiles/hbm_traffic.json[dragon] must carry the source hash of the kernels in the tree: a kernel change without a new
+    counter pass would make the driver's bench line report `frac: null`."""
+    from craytracer_amd import build
+    import os
+    path = os.path.join(bench.ROOT, 'profiles', 'hbm_traffic.json')
+    ent = json.load(open(path))['dragon']
+    assert ent.get('source_hash') == build.source_hash(), 're-run tools/profile_round.sh + tools/adopt_profile.sh for the current kernels'
+    t, prov, _ = bench.committed_traffic('dragon', build.source_hash(), 9.0)
+    assert t and 'refused' not in prov
