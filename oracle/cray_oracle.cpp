@@ -1843,6 +1843,18 @@ void orc_bounds_sum(const double* a6, const double* b6, double* out6) {
 uint64_t orc_partition_by(int64_t* data, uint64_t n, int mode, int64_t a, int64_t b) {
     return partition_by(data, (size_t)n, [&](const int64_t& x) { return mode == 0 ? (x > a) : (((x % a) + a) % a == b); });
 }
+/* Frame (src/transformation.rs:494-535): three orthonormal vectors; from_xy normalises x, y and takes z = normalized(x cross y)
+ * (:502-509); from_local = x t.x + y t.y + z t.z (:518-520, the Normal impl :528-530 is the same arithmetic), to_local =
+ * (v . x, v . y, v . z) (:522-524, :532-534).  No code of the reference's hot path uses it; restated for its tests only
+ * (tests/test_transformation.rs:186-225). */
+void orc_frame(const double* fx, const double* fy, const double* v, double* from_local, double* to_local) {
+    const V3 x = normalized(v3(fx[0], fx[1], fx[2])), y = normalized(v3(fy[0], fy[1], fy[2]));
+    const V3 z = normalized(cross(v3(fx[0], fx[1], fx[2]), v3(fy[0], fy[1], fy[2])));
+    const V3 t = v3(v[0], v[1], v[2]);
+    const V3 f = x * t.x + y * t.y + z * t.z;
+    from_local[0] = f.x; from_local[1] = f.y; from_local[2] = f.z;
+    to_local[0] = dot(t, x); to_local[1] = dot(t, y); to_local[2] = dot(t, z);
+}
 void orc_sampling_fn(int which, double u, double v, const double* n, double* out) {
     int af = 0;
     if (which == 0) { sample_disk(u, v, &out[0], &out[1]); }

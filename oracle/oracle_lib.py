@@ -86,6 +86,7 @@ def lib():
         L.orc_vec_op.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
         L.orc_col_op.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
         L.orc_bounds_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_frame.argtypes = [C.c_void_p] * 5
         L.orc_partition_by.restype = C.c_uint64
         L.orc_partition_by.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int64, C.c_int64]
         L.orc_set_libm_mode.argtypes = [C.c_int]

@@ -350,3 +350,18 @@ def test_bounds_sum():
     assert bsum((0, 0, 0, 1, 0, 0), (0, 0, 0, 1, 0, 0)) == (0, 0, 0, 1, 0, 0)
     assert bsum((0, 0, 0, 1, 0, 0), (0, 0, 0, 0, 1, 0)) == (0, 0, 0, 1, 1, 0)
     assert bsum((0, 0, 0, 1, 1, 1), (2, 2, 2, 3, 3, 3)) == (0, 0, 0, 3, 3, 3)
+
+
+# --- tests/test_transformation.rs:186-225 (mod frame): Frame::from_xy, from_local, to_local for Vector and Normal -------------
+def test_frame_from_xy_permutes_the_axes():
+    X, Y, Z = (1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0)
+
+    def frame(v):
+        a, b = np.zeros(3), np.zeros(3)
+        L.orc_frame(f64(*Y).ctypes.data, f64(*Z).ctypes.data, f64(*v).ctypes.data, a.ctypes.data, b.ctypes.data)   # x -> y, y -> z, z -> x
+        return tuple(a), tuple(b)
+    # the Vector and the Normal test assert the same values (the Normal impl converts the same sums)
+    assert frame(X) == (Y, Z)
+    assert frame(Y) == (Z, X)
+    assert frame(Z) == (X, Y)
+    assert frame((1.0, -1.0, 0.0)) == ((0.0, 1.0, -1.0), (-1.0, 0.0, 1.0))
