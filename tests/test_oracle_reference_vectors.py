@@ -358,8 +358,9 @@ def test_frame_from_xy_permutes_the_axes():
 
     def frame(v):
         a, b = np.zeros(3), np.zeros(3)
-        L.orc_frame(f64(*Y).ctypes.data, f64(*Z).ctypes.data, f64(*v).ctypes.data, a.ctypes.data, b.ctypes.data)   # x -> y, y -> z, z -> x
-        return tuple(a), tuple(b)
+        fx, fy, vv = f64(*Y), f64(*Z), f64(*v)       # Frame::from_xy(&Y, &Z): x -> y, y -> z, z -> x
+        L.orc_frame(fx.ctypes.data, fy.ctypes.data, vv.ctypes.data, a.ctypes.data, b.ctypes.data)
+        return tuple(float(t) for t in a), tuple(float(t) for t in b)
     # the Vector and the Normal test assert the same values (the Normal impl converts the same sums)
     assert frame(X) == (Y, Z)
     assert frame(Y) == (Z, X)
