@@ -95,7 +95,9 @@ BUILD_MODE = None
 
 
 def lib():
-    """Load libcray_hip.so (building it if the sources are newer). Raises if it cannot be loaded."""
+    """Load libcray_hip.so (building it if the sources are newer). Raises if it cannot be loaded.
+    In a process that also uses torch, import torch BEFORE the first call: torch brings its own HIP runtime, and a library
+    loaded first binds the system one — two runtimes in one process, the second of which sees no device."""
     global _lib, BUILD_MODE
     if _lib is not None:
         return _lib
