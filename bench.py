@@ -36,9 +36,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 B_NODE, B_TRI, B_OTHER, B_RAY = 64, 72, 48, 88
 # k_shade, per unit: a shaded path reads queue entry + hit primitive id (8 B); a path that hit something
 # also reads its ray, hit record, beta, Sobol seed, primitive and shading record and (emitters, escapes aside) goes on:
-B_SHADE_IN, B_SHADE_HIT = 8, 48 + 24 + 24 + 4 + 16 + 120
-B_SHADE_SHADOW = 56 + 24 + 4          # a stored shadow ray: origin/direction/tmax + gated NEE term + queue entry
-B_SHADE_NEXT = 48 + 24 + 8 + 4 + 4    # a continued path: new ray, beta, prev pdf, flags + queue entry
+B_SHADE_IN, B_SHADE_HIT = 8, 48 + 24 + 24 + 4 + 4 + 16 + 120   # ... + its original path index (round 3: compacted state)
+B_SHADE_SHADOW = 56 + 24 + 4 + 4 + 4          # a stored shadow ray: origin/direction/tmax + gated NEE term + original path, start primitive + queue entry
+B_SHADE_NEXT = 48 + 24 + 8 + 4 + 4 + 4 + 4 + 4    # a continued path: new ray, beta, prev pdf, flags, pixel seed, original path, start primitive + queue entry
 
 WORKLOADS = {
     # name: scene factory kwargs + 'scene' (factory in craytracer_amd.scenes) + 'label' (which BASELINE.json config it is)
