@@ -227,53 +227,97 @@ def main():
             sum(s['trace_any_ms'] for s in stats), sum(s['shade_ms'] for s in stats), sum(s['other_ms'] for s in stats),
             float(sum(s['shade_launches'] for s in stats))]
 
-    # --- roofline of the dominant kernel family: BVH traversal (k_trace<closest> for bounce 0, k_trace_mixed =
-    # shadow rays of bounce b + segments of bounce b+1, k_trace<any> for the last bounce), this rank's share.
-    # Algorithmic bytes come from one counting pass over the queries the timed frames actually traverse
-    # (count_traversal=2: zero-term shadow rays skipped, like in the timed frames).
+    # --- roofline of the dominant kernel: k_trace_mixed (the shadow rays of bounce b + the path segments of bounce b + 1 in one
+    # persistent launch: 70 % of the frame), this rank's share; beside it the same accounting for the whole traversal family
+    # (k_trace<closest> for bounce 0 + k_trace_mixed + k_trace<any> for the last bounce: one code body, trace_body).
+    # Algorithmic bytes are counted, not estimated: counting passes (count_traversal = 2: zero-term shadow rays skipped, as in the
+    # timed frames) over exactly the queries the timed kernels traverse.  The counters of a frame are per query KIND, not per launch,
+    # so the mixed kernel's share is obtained from two more counting passes over the same scene at other depths: every path behaves
+    # identically up to the depth limit, hence
+    #   closest queries of bounce 0        = closest queries of the frame at max_depth 1            (not traced by k_trace_mixed)
+    #   shadow queries of bounces 0..D-2   = shadow queries of the frame at max_depth D - 1         (all traced by k_trace_mixed)
     roofline = None
     counts = None
     if args.count_pass:
         film_dev = torch.zeros((H, W, 3), dtype=torch.float32, device='cuda')
         _, cst = dev.render(seed=0, rank=rank, world_size=world, out_device_ptr=film_dev.data_ptr(), count_traversal=2)
-        del film_dev
         counts = cst
-        tri = cst['closest_tri_tests'] + cst['shadow_tri_tests']
-        other = cst['closest_prims'] + cst['shadow_prims'] - tri
-        nodes = cst['closest_nodes'] + cst['shadow_nodes']
+
+        def alg_bytes(nodes, prims, tri, traced):
+            return B_NODE * nodes + B_TRI * tri + B_OTHER * (prims - tri) + B_RAY * traced
+
         traced = cst['closest_rays'] + cst['shadow_rays'] - cst['shadow_skipped']
-        alg_bytes_frame = B_NODE * nodes + B_TRI * tri + B_OTHER * other + B_RAY * traced
-        k_ms, k_launches = kern[0], kern[1]
-        launches_per_frame = k_launches / max(1, args.steps)
-        avg_ms = k_ms / max(1.0, k_launches)
-        achieved = (alg_bytes_frame * args.steps) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        alg_family = alg_bytes(cst['closest_nodes'] + cst['shadow_nodes'], cst['closest_prims'] + cst['shadow_prims'],
+                               cst['closest_tri_tests'] + cst['shadow_tri_tests'], traced)
+        alg_mixed = traced_mixed = None
+        depth = wl['max_depth']
+        if scene is not None and depth >= 2 and kern[3] > 0:
+            def at_depth(k):
+                d = scene.desc()
+                old = d.max_depth
+                d.max_depth = k
+                try:
+                    h = backend.HostScene(scene, resident=True)
+                finally:
+                    d.max_depth = old
+                dv = ctx.upload(h)
+                try:
+                    return dv.render(seed=0, rank=rank, world_size=world, out_device_ptr=film_dev.data_ptr(), count_traversal=2)[1]
+                finally:
+                    dv.close()
+            c1, cm = at_depth(1), at_depth(depth - 1)
+            traced_mixed = (cst['closest_rays'] - c1['closest_rays']) + (cm['shadow_rays'] - cm['shadow_skipped'])
+            alg_mixed = alg_bytes((cst['closest_nodes'] - c1['closest_nodes']) + cm['shadow_nodes'],
+                                  (cst['closest_prims'] - c1['closest_prims']) + cm['shadow_prims'],
+                                  (cst['closest_tri_tests'] - c1['closest_tri_tests']) + cm['shadow_tri_tests'], traced_mixed)
+        del film_dev
+        fam_ms, fam_launches = kern[0], kern[1]
+        mix_ms = kern[3]
+        mix_launches = float(sum(s['trace_mixed_launches'] for s in stats))
         # HBM bytes the PMC counters saw for these kernels.  Counters need their own rocprofv3 --pmc passes, so this run cannot
         # measure them: they come from the committed profile of THIS build (tools/profile_round.sh -> profiles/hbm_traffic.json),
         # and are refused when the profile is of another build (source hash of the kernels differs from the loaded library's).
-        traffic, provenance, ent = committed_traffic(args.workload, hip_build.loaded_hash(), launches_per_frame, world, args.precision)
-        hbm_gbs = traffic / (avg_ms * 1e-3) / 1e9 if traffic and avg_ms > 0 else None
-        roofline = {'bound': 'hbm',
-                    'kernel': 'k_trace family (k_trace<closest> + k_trace_mixed + k_trace<any>)',
-                    # achieved / frac: HBM bytes the counters saw per launch over the live HIP-event time of a launch, against the
-                    # 8 TB/s spec.  null when no counter profile of this build is committed (never an algorithmic figure).
-                    'achieved': round(hbm_gbs, 1) if hbm_gbs else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(hbm_gbs / HBM_PEAK_GBS, 5) if hbm_gbs else None, 'traffic': traffic,
-                    'traffic_provenance': provenance,
-                    'avg_launch_ms': round(avg_ms, 4), 'launches_per_step': launches_per_frame,
-                    # the algorithmic bytes of SURVEY.md section 8(d) (counted, not estimated) and the rate they would need if none of
-                    # them were served by L2 / Infinity Cache: a work measure, NOT a bandwidth the chip delivered
-                    'alg_bytes_per_launch': round(alg_bytes_frame / max(1.0, launches_per_frame)),
-                    'alg_bytes_rate_GBs': round(achieved, 2), 'alg_bytes_per_ray': round(alg_bytes_frame / max(1, traced), 1),
-                    'alg_over_traffic': round(alg_bytes_frame / max(1.0, launches_per_frame) / traffic, 2) if traffic else None,
-                    'bound_note': 'HBM is the roofline the north star prices this path against; the counters of the same build say the units that '
-                                  'bind it are the texture addresser (16-B lane loads of 128-B records) and f64 VALU issue: other_bounds'}
-        if traffic and ent.get('units'):
-            # utilisations of the units that do bind the path, from the SQ / TA passes of the same profiled build (each <= 1)
+        traffic_frame, provenance, ent = committed_traffic(args.workload, hip_build.loaded_hash(), 1.0, world, args.precision)
+
+        def block(kernel, ms, launches, hbm_per_frame, alg_frame, n_rays):
+            per_frame = launches / max(1, args.steps)
+            avg_ms = ms / max(1.0, launches)
+            t = round(hbm_per_frame / max(1.0, per_frame)) if hbm_per_frame else None
+            gbs = t / (avg_ms * 1e-3) / 1e9 if t and avg_ms > 0 else None
+            out = {'kernel': kernel,
+                   # achieved / frac: HBM bytes the counters saw per launch over the live HIP-event time of a launch, against the
+                   # 8 TB/s spec.  null when no counter profile of this build is committed (never an algorithmic figure).
+                   'achieved': round(gbs, 1) if gbs else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                   'frac': round(gbs / HBM_PEAK_GBS, 5) if gbs else None, 'traffic': t,
+                   'avg_launch_ms': round(avg_ms, 4), 'launches_per_step': per_frame}
+            if alg_frame:
+                # the algorithmic bytes of SURVEY.md section 8(d) and the rate they would need if none of them were served by
+                # L1 / L2 / Infinity Cache: a work measure, NOT a bandwidth the chip delivered
+                out.update({'alg_bytes_per_launch': round(alg_frame / max(1.0, per_frame)),
+                            'alg_bytes_rate_GBs': round(alg_frame * args.steps / (ms * 1e-3) / 1e9, 2) if ms > 0 else None,
+                            'alg_bytes_per_ray': round(alg_frame / max(1, n_rays), 1),
+                            'alg_over_traffic': round(alg_frame / max(1.0, per_frame) / t, 2) if t else None})
+            return out
+
+        mixed_frame = ent.get('mixed_bytes_per_frame') if traffic_frame else None
+        if mix_launches > 0:
+            roofline = block('k_trace_mixed (shadow rays of bounce b + path segments of bounce b + 1)', mix_ms, mix_launches, mixed_frame, alg_mixed, traced_mixed)
+            roofline['share_of_step'] = round(mix_ms / args.steps / (elapsed / args.steps * 1e3), 3)
+            roofline['k_trace_family'] = block('k_trace<closest> (bounce 0) + k_trace_mixed + k_trace<any> (last bounce)', fam_ms, fam_launches, traffic_frame, alg_family, traced)
+        else:   # traversal counting frames and max_depth 1 have no mixed launches: the family is the dominant kernel
+            roofline = block('k_trace family (k_trace<closest> + k_trace<any>)', fam_ms, fam_launches, traffic_frame, alg_family, traced)
+        roofline['bound'] = 'hbm'
+        roofline['traffic_provenance'] = provenance
+        roofline['bound_note'] = ('HBM is the roofline the north star prices this path against; the counters of the same build say what binds the kernel '
+                                  'is per CU: L1 line fills at the rate a CU can keep in flight, texture addresser and f64 VALU issue at ~0.7 each: other_bounds')
+        if traffic_frame and ent.get('units'):
+            # utilisations of the units that do bind the path, from the SQ / TA / TCC / TCP passes of the same profiled build
             u = ent['units']
             roofline['other_bounds'] = {'source': ent.get('units_source'), 'kernels': {
                 k: {'ta_busy_share': v.get('ta_busy'), 'valu_issue_share_min': v.get('valu_issue_share_min'),
                     'valu_lane_utilisation': v.get('valu_lane_utilisation'), 'wait_share_of_wave_cycles': v.get('wait_any_share_of_wave_cycles'),
                     'l2_hit_rate': v.get('tcc_hit_rate'), 'l1_fill_bytes_per_clk_per_cu': v.get('l1_fill_bytes_per_clk_per_cu')} for k, v in u.items()}}
+        traffic = traffic_frame
         # the second kernel of the frame: k_shade (path state + shading records)
         n_shaded = cst['closest_rays']                      # every traced segment is shaded once
         n_hit = cst.get('closest_hits', 0) or n_shaded      # segments that hit something
@@ -298,7 +342,7 @@ def main():
         try:
             stream_gbs = ctx.measure_stream_read(4 << 30, 5)
             roofline['measured_stream_read_GBs'] = round(stream_gbs, 1)
-            if roofline['achieved']:
+            if roofline.get('achieved'):
                 roofline['frac_of_measured_stream'] = round(roofline['achieved'] / stream_gbs, 5)
         except Exception as e:  # measurement aid only
             log('stream-read measurement skipped: %s' % e)

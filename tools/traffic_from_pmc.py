@@ -56,6 +56,8 @@ if __name__ == '__main__':
         if k.startswith('k_trace'):
             tot += (v.get('fetch_bytes_per_launch', 0) + v.get('write_bytes_per_launch', 0)) * v['launches']
             launches += v['launches']
+    entry['mixed_bytes_per_frame'] = round(sum((v.get('fetch_bytes_per_launch', 0) + v.get('write_bytes_per_launch', 0)) * v['launches']
+                                               for k, v in entry['kernels'].items() if k.startswith('k_trace_mixed')))
     entry['trace_launches'] = launches                       # of the profiled run: ONE frame (bench.py --steps 1 --warmup 0)
     entry['trace_bytes_per_launch'] = round(tot / max(1, launches))
     entry['trace_bytes_per_frame'] = round(tot)              # what bench.py divides by ITS launches per frame
