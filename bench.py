@@ -188,6 +188,11 @@ def main():
             log('scene broadcast to %d ranks: %.2f s' % (world, time.time() - tb))
     assert (dev.width, dev.height) == (W, H)
     dev.precision = args.precision
+    if world > 1:
+        # the shard's tiles: 32 x 32 instead of the reference's 64 x 64.  The film does not depend on the tile shape (every pixel is
+        # accumulated on one GPU in the single-GPU order); four times as many tiles spread the expensive image regions over the ranks
+        # more evenly: +-0.7 % instead of +-3 % between the ranks of an 8-way shard (profiles/r03_tile_shape_probe.log)
+        dev.tile = (32, 32)
     if args.precision != 'f64':
         args.count_pass = 0   # the traversal counters (and with them the algorithmic bytes) are defined by the f64 traversal
 
@@ -387,7 +392,7 @@ def main():
             'data': 'synthetic',
             'config': {'workload': '%s, %s triangles, %dx%d, %d spp, depth %d'
                                    % (wl['label'], n_tris, W, H, wl['spp'], wl['max_depth']),
-                       'parallelism': ('tile-shard x%d; C ABI: cray_comm_init + %s + cray_render_gather (RCCL ncclSend/ncclRecv of Film tiles to rank 0)'
+ 'parallelism': ('tile-shard x%d (32x32 tiles, tile %% N == rank); C ABI: cray_comm_init + %s + cray_render_gather (RCCL ncclSend/ncclRecv of Film tiles to rank 0)'
                                        % (world, 'per-rank scene build' if args.replicate_host else 'cray_scene_broadcast (ncclBroadcast)')) if world > 1 else 'single GPU',
                        'seconds_per_frame': round(elapsed / args.steps, 4),
                        'mpaths_per_s': round(total_paths / elapsed / 1e6, 2),

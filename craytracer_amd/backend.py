@@ -400,6 +400,9 @@ class DeviceScene:
     independent_sampler = False
     #: 'f64' (the reference's arithmetic) or 'f32' (fast mode: f32 traversal, NOT bit-exact; cray_render_params.precision)
     precision = 'f64'
+    #: (tile_width, tile_height) of the shard and of the pixel order inside a pass; None = the reference's 64 x 64 (craytracer.rs:232-233).
+    #: The film does not depend on it; 32 x 32 balances the ranks of a multi-GPU frame better.
+    tile = None
 
     def params(self, seed=0, rank=0, world_size=1, sample_range=None, count_traversal=False, max_paths_in_flight=0):
         p = RenderParams()
@@ -411,6 +414,8 @@ class DeviceScene:
         elif self.independent_sampler:
             p.sampler = 2
         p.seed, p.rank, p.world_size = seed, rank, world_size
+        if self.tile is not None:
+            p.tile_width, p.tile_height = self.tile
         if sample_range is not None:
             p.sample_begin, p.sample_end = sample_range
         p.count_traversal = int(count_traversal)  # True/1: every reference query; 2: only the traversed ones

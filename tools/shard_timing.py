@@ -20,6 +20,7 @@ def main():
     ap.add_argument('--worlds', default='1,2,4,8')
     ap.add_argument('--reps', type=int, default=2)
     ap.add_argument('--ranks', default='', help='comma list: time only these ranks of each world')
+    ap.add_argument('--tile', type=int, default=64, help='edge of the square shard tiles (bench.py --gpus N uses 32)')
     args = ap.parse_args()
     import torch
     import bench
@@ -30,6 +31,7 @@ def main():
     host = backend.HostScene(scene)
     ctx = backend.Context(0, stream=torch.cuda.current_stream().cuda_stream)
     dev = ctx.upload(host)
+    dev.tile = (args.tile, args.tile)
     film = torch.zeros((H, W, 3), dtype=torch.float32, device='cuda')
     w0 = int(args.worlds.split(',')[0])
     dev.render(seed=0, rank=0, world_size=w0, out_device_ptr=film.data_ptr(), sample_range=(0, min(8, wl['spp'])))  # warm-up
