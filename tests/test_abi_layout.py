@@ -152,6 +152,27 @@ def test_abi_version_constant(rust):
     assert re.search(r'CRAY_ABI_VERSION: u32 = (\d+)', rs).group(1) == re.search(r'#define CRAY_ABI_VERSION (\d+)', h).group(1)
 
 
+def test_rust_constants_match_the_headers():
+    """Every `pub const CRAY_*` of the Rust file has the value the headers give the same name (enum members and #defines)."""
+    with open(RS) as fh:
+        rs = fh.read()
+    text = ''
+    for h in ('cray_scene_desc.h', 'cray.h', 'cray_host.h', 'cray_cry.h', 'cray_io.h'):
+        with open(os.path.join(ROOT, 'include', h)) as fh:
+            text += re.sub(r'/\*.*?\*/', '', fh.read(), flags=re.S)
+    c_vals = {}
+    for body in re.findall(r'enum\s*\{(.*?)\}', text, flags=re.S):
+        for name, val in re.findall(r'(CRAY_\w+)\s*=\s*(-?\d+)', body):
+            c_vals[name] = int(val)
+    for name, val in re.findall(r'#define\s+(CRAY_\w+)\s+(-?\d+)\b', text):
+        c_vals[name] = int(val)
+    consts = re.findall(r'pub const (CRAY_\w+): \w+ = (-?\d+);', rs)
+    assert len(consts) >= 40
+    for name, val in consts:
+        assert name in c_vals, '%s is not a constant of include/' % name
+        assert c_vals[name] == int(val), '%s: %s in Rust, %d in C' % (name, val, c_vals[name])
+
+
 def test_rust_functions_match_the_headers():
     """Every extern fn of the Rust block is declared in a header with the same number of parameters."""
     with open(RS) as fh:
