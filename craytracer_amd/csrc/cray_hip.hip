@@ -1871,15 +1871,26 @@ extern "C" int cray_comm_barrier(cray_ctx* c) {
 // Every rank passes the return code of the work it did alone (0 or a negative CRAY_ERR_*); every rank gets the worst of
 // them.  Real RCCL has no timeout: a rank that returned early from a collective sequence leaves its peers waiting in
 // ncclRecv / ncclBroadcast for ever, so the ranks agree BEFORE any transfer whose other end might be missing.
-static int comm_agree(cray_ctx* c, int local) {
+// `shape` (optional, n_shape <= 8 values): numbers every rank must pass identically for the exchange to line up — film size, tile
+// shape, sample count.  Ranks that disagree would post receives and sends of different lengths, so a mismatch is an error on all.
+static int comm_agree(cray_ctx* c, int local, const double* shape = nullptr, int n_shape = 0) {
     if (!c->comm || c->comm_world == 1) return local;
     char mine[sizeof(g_err)];
     memcpy(mine, g_err, sizeof(mine));   // the all-reduce below may overwrite the thread's message
-    double v = (double)local;
-    const int e = cray_comm_allreduce_f64(c, &v, 1, CRAY_REDUCE_MIN);
+    double v[1 + 2 * 8];
+    v[0] = (double)local;
+    if (n_shape > 8) n_shape = 8;
+    for (int i = 0; i < n_shape; i++) { v[1 + 2 * i] = shape[i]; v[2 + 2 * i] = -shape[i]; }   // MIN of x and of -x: min and max in one reduction
+    const int e = cray_comm_allreduce_f64(c, v, 1 + 2 * n_shape, CRAY_REDUCE_MIN);
     if (e) return e;                     // the collective itself failed: nothing to agree with
     if (local) { memcpy(g_err, mine, sizeof(mine)); return local; }
-    if (v != 0.0) { set_last_error("another rank failed with code %d before the exchange (its own message has the detail)", (int)v); return (int)v; }
+    if (v[0] != 0.0) { set_last_error("another rank failed with code %d before the exchange (its own message has the detail)", (int)v[0]); return (int)v[0]; }
+    for (int i = 0; i < n_shape; i++)
+        if (v[1 + 2 * i] != -v[2 + 2 * i]) {
+            set_last_error("the ranks disagree on argument %d of the exchange (film size / tile shape / samples): %g here, between %g and %g over the ranks",
+                           i, shape[i], v[1 + 2 * i], -v[2 + 2 * i]);
+            return CRAY_ERR_INVALID;
+        }
     return CRAY_OK;
 }
 
@@ -1965,7 +1976,11 @@ extern "C" int cray_render_gather(cray_ctx* c, cray_scene* s, const cray_render_
     }
     if (!e) e = render_local(c, s, &prm, stats);
     if (!e) e = gather_prepare(c, s->dev.film_w, s->dev.film_h, prm.tile_width, prm.tile_height);
-    if ((e = comm_agree(c, e))) return e;
+    {
+        const double shape[5] = {s ? (double)s->dev.film_w : 0.0, s ? (double)s->dev.film_h : 0.0, (double)prm.tile_width, (double)prm.tile_height,
+                                 s ? (double)s->dev.num_samples : 0.0};
+        if ((e = comm_agree(c, e, shape, 5))) return e;
+    }
     const DevScene& d = s->dev;
     if ((e = gather_tiles(c, d.film_w, d.film_h, prm.tile_width, prm.tile_height, c->film, (float)d.num_samples, dst))) return e;
     if ((e = finish_output(c, &prm, c->comm_rank == 0 ? out_rgb : nullptr, film_floats))) return e;
@@ -1987,7 +2002,10 @@ extern "C" int cray_film_gather(cray_ctx* c, uint32_t W, uint32_t H, uint32_t tw
     float* dst = nullptr;
     if (!e && c->comm_rank == 0) e = output_target(c, &prm, out_rgb, film_floats, &dst);
     if (!e) e = gather_prepare(c, W, H, tw, th);
-    if ((e = comm_agree(c, e))) return e;
+    {
+        const double shape[4] = {(double)W, (double)H, (double)tw, (double)th};
+        if ((e = comm_agree(c, e, shape, 4))) return e;
+    }
     if ((e = gather_tiles(c, W, H, tw, th, local_film, 1.0f, dst))) return e;
     return finish_output(c, &prm, c->comm_rank == 0 ? out_rgb : nullptr, film_floats);
 }

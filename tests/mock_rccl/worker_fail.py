@@ -52,6 +52,12 @@ assert rc != 0, 'rank %d: gather with a failing peer returned 0' % rank
 msg = L.cray_last_error().decode()
 assert ('bad tile' in msg) if rank == 1 else ('another rank failed' in msg), msg
 
+# 3b. ranks that pass different tile shapes would post sends and receives of different lengths: an error on every rank
+p = scene.params(seed=3)
+p.tile_width = 32 if rank == 1 else 64
+rc = L.cray_render_gather(ctx._h, scene._h, C.byref(p), C.c_void_p(film.ctypes.data) if rank == 0 else None, C.byref(st))
+assert rc != 0 and 'disagree' in L.cray_last_error().decode(), (rank, rc, L.cray_last_error().decode())
+
 # 4. and the next frame is fine: the film of the gather equals the unsharded film
 got, _ = scene.render_gather(seed=3)
 if rank == 0:
