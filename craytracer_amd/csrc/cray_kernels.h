@@ -752,8 +752,19 @@ __device__ __forceinline__ uint32_t lds_reserve(unsigned int* count) {
 // The reference's `main` runs mode 0 (path integrator + Sobol, craytracer.rs:159-160, 361); the others are its selectable
 // alternatives and run on the all-features instantiation only.
 enum { kModeSimple = 1, kModeUniform = 2, kModeLdsTables = 4, kModeIndependent = 8 };
+// Waves per SIMD the instantiation is compiled for.  Two everywhere (the double-double sin / cos and the emitters' 4x4 transforms
+// keep the live set above 168 registers) except the textured instantiations of the default mode — the staircase.cry class — whose
+// dependent texel fetches gain more from a third wave than its 32 spilled registers cost (round 3, after the Sobol nibble tables
+// freed ~40 registers: k_shade 190 -> 177 ms at configs[3]; the matte / conductor instantiations fit 168 without a spill and do not gain).
+constexpr int shade_waves(uint32_t F, int MODE) {
+#ifdef CRAY_SHADE_WAVES_FORCE
+    return CRAY_SHADE_WAVES_FORCE;
+#else
+    return ((MODE & ~kModeLdsTables) == 0 && CRAY_HAS(F, SF_TEX_IMAGE) && F != SF_ALL) ? 3 : CRAY_SHADE_WAVES;
+#endif
+}
 template <uint32_t F, int MODE = 0>
-__global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc, PathState ps, PathState po, const uint32_t* __restrict__ queue,
+__global__ void __launch_bounds__(kBlock, shade_waves(F, MODE)) k_shade(DevScene sc, PathState ps, PathState po, const uint32_t* __restrict__ queue,
                                                   const unsigned int* __restrict__ n_ptr, uint32_t n_fixed, uint32_t bounce,
                                                   uint32_t spp_pass, uint32_t s_lo, uint32_t* __restrict__ next_queue,
                                                   unsigned int* next_count, uint32_t* __restrict__ shadow_queue,
@@ -801,6 +812,13 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
             sc.images = static_cast<const cray_image*>(stage(sc.images, sc.n_images * (uint32_t)sizeof(cray_image)));
             sc.gamma_lut = static_cast<const double*>(stage(sc.gamma_lut, 256u * 8u));
         }
+        __syncthreads();
+    }
+    // the two Sobol sets this bounce draws from (dimensions 4 + 8 b .. 11 + 8 b), folded into nibble tables once per block
+    constexpr bool kSobolLut = !kSimple && !kUniform && !kIndependent;
+    __shared__ uint2 l_sob[kSobolLut ? 128 : 1];
+    if (kSobolLut) {
+        if (threadIdx.x < 128u) sobol_fill_lut(sc.sobol, 1u + 2u * bounce + (threadIdx.x >> 6), threadIdx.x & 63u, l_sob + (threadIdx.x & 64u));
         __syncthreads();
     }
     // tile size: kShadeTile for the big launches, smaller (down to one pass of the block) when the launch would otherwise
@@ -902,8 +920,8 @@ __global__ void __launch_bounds__(kBlock, CRAY_SHADE_WAVES) k_shade(DevScene sc,
                     sa[0] = v7[0]; sa[1] = v7[1]; sa[2] = v7[2]; sa[3] = v7[3];
                     sb[0] = v7[4]; sb[1] = v7[5]; sb[2] = v7[6]; sb[3] = 0.0;
                 } else {
-                    sobol4(sc.sobol, sidx, 1 + 2 * bounce, h, sa);  // material 1D, material 2D, light index
-                    sobol4(sc.sobol, sidx, 2 + 2 * bounce, h, sb);  // light 1D, light 2D, roulette
+                    sobol4_lut(l_sob, sidx, 1 + 2 * bounce, h, sa);       // material 1D, material 2D, light index
+                    sobol4_lut(l_sob + 64, sidx, 2 + 2 * bounce, h, sb);  // light 1D, light 2D, roulette
                 }
 
                 // emission at the hit (:106-126)

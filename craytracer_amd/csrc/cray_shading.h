@@ -103,6 +103,37 @@ __device__ __forceinline__ void sobol4(const uint16_t* __restrict__ table, uint3
     out[3] = (double)unit_float(__brev(lk_scramble(b >> 16, lk_seed_hash(s, 0xb40cc1b8u))));
 }
 
+// sample_4d through nibble tables (round 3).  Which direction vectors are XORed depends on the top 16 bits of the scrambled
+// index; `sobol4` walks them bit by bit (16 x {extract, 2 and, 2 xor} = 80 VALU instructions per call, twice per path and
+// bounce: the largest single block of k_shade's ~1 600).  A kernel that uses a set for a whole launch can instead fold the
+// set's 16 vectors into four tables of 16 XOR combinations (nibble j of the index -> the XOR of its set bits' vectors, both
+// lane pairs: 64 x 8 B) once per block in LDS and XOR four entries: the same word, by associativity of XOR.
+//   T[16 j + v] = XOR over t in 0..3 with bit (3 - t) of v set of  vectors[4 j + t]      (bit 0 of the loop = index bit 31)
+__device__ __forceinline__ void sobol_fill_lut(const uint16_t* __restrict__ table, uint32_t set, uint32_t entry, uint2* __restrict__ lut) {
+    const uint2* v = reinterpret_cast<const uint2*>(table + (size_t)set * 64);
+    const uint32_t j = entry >> 4, nv = entry & 15u;
+    uint2 acc = make_uint2(0u, 0u);
+#pragma unroll
+    for (uint32_t t = 0; t < 4; t++)
+        if ((nv >> (3u - t)) & 1u) { const uint2 w = v[4 * j + t]; acc.x ^= w.x; acc.y ^= w.y; }
+    lut[entry] = acc;
+}
+__device__ __forceinline__ void sobol4_lut(const uint2* __restrict__ lut, uint32_t index, uint32_t set, uint32_t seed, double out[4]) {
+    const uint32_t idx = lk_scramble(__brev(index), lk_seed_hash(seed, 0x79c68e4au));   // only the top 16 bits select vectors
+    uint32_t a = 0, b = 0;  // a = lanes 0|1, b = lanes 2|3 (u16 each)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint2 w = lut[16 * j + ((idx >> (28 - 4 * j)) & 15u)];
+        a ^= w.x;
+        b ^= w.y;
+    }
+    const uint32_t s = set ^ seed;
+    out[0] = (double)unit_float(__brev(lk_scramble(a & 0xffffu, lk_seed_hash(s, 0x912f69bau))));
+    out[1] = (double)unit_float(__brev(lk_scramble(a >> 16, lk_seed_hash(s, 0x174f18abu))));
+    out[2] = (double)unit_float(__brev(lk_scramble(b & 0xffffu, lk_seed_hash(s, 0x691e72cau))));
+    out[3] = (double)unit_float(__brev(lk_scramble(b >> 16, lk_seed_hash(s, 0xb40cc1b8u))));
+}
+
 // =============================================================================
 // sampling_fns (src/sampling.rs:11-65)
 // =============================================================================
