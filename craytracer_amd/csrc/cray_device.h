@@ -166,6 +166,7 @@ struct Counters {
     unsigned long long closest_tri, shadow_tri;
     unsigned long long nonfinite, stack_overflow, shadow_skipped, closest_hits;
     unsigned int n_active[2], n_shadow, trace_head;
+    unsigned int shade_head, pad_head_;   // k_shade's tile dispenser (zeroed before every launch)
     unsigned long long diag[32];  // k_trace lane-occupancy diagnostics (CRAY_TRACE_DIAG builds only)
     // Third level of the traversal stack (LDS -> scratch -> here): entries kStackDepth.. of every lane, in global
     // memory as [entry][global thread].  Allocated by the runtime only after a frame overflowed the first two levels.

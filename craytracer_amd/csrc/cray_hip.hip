@@ -59,7 +59,7 @@ struct cray_ctx {
     unsigned int refill_min = 28, refill_min_b0 = 64, refill_min_any = 40;
     int trace_blocks_per_cu = 4;
     int trace32_blocks_per_cu = 4;
-    int shade_blocks_per_cu = 4;
+    int shade_blocks_per_cu = 0;   // 0: the occupancy of the instantiation that runs (launch_shade)
     // path-state pool
     size_t capacity = 0;
     std::vector<void*> state_allocs;
@@ -243,6 +243,14 @@ int grid_for(const cray_ctx* c, size_t n, int blocks_per_cu) {
     return (int)(want < cap ? want : cap);
 }
 
+// resident blocks per CU of a kernel, as the runtime computes it from the code object's registers and LDS.  The grid-stride kernels
+// size their grids as a multiple of it: a grid that is not one leaves a last round with part of the chip idle.
+int resident_blocks(const void* kernel, int threads, int fallback) {
+    int o = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, kernel, threads, 0) != hipSuccess || o < 1) { (void)hipGetLastError(); o = fallback; }
+    return o;
+}
+
 void fill_stats(const Counters& h, cray_stats* st) {
     st->closest_rays = h.closest_rays; st->shadow_rays = h.shadow_rays + h.shadow_skipped; st->shadow_skipped = h.shadow_skipped;
     st->closest_nodes = h.closest_nodes; st->closest_prims = h.closest_prims;
@@ -322,7 +330,7 @@ extern "C" int cray_ctx_create(int device_id, void* stream, cray_ctx** out) {
     c->refill_min_b0 = (unsigned int)env_int("CRAY_REFILL_MIN_B0", 1, 64, (int)c->refill_min_b0);
     c->refill_min_any = (unsigned int)env_int("CRAY_REFILL_MIN_ANY", 1, 64, (int)c->refill_min_any);
     c->trace_blocks_per_cu = env_int("CRAY_TRACE_BLOCKS_PER_CU", 1, 16, c->trace_blocks_per_cu);
-    c->shade_blocks_per_cu = env_int("CRAY_SHADE_BLOCKS_PER_CU", 1, 64, c->shade_blocks_per_cu);
+    c->shade_blocks_per_cu = env_int("CRAY_SHADE_BLOCKS_PER_CU", 0, 64, c->shade_blocks_per_cu);
     c->trace32_blocks_per_cu = env_int("CRAY_TRACE32_BLOCKS_PER_CU", 1, 16, c->trace32_blocks_per_cu);
     *out = c;
     return CRAY_OK;
@@ -983,28 +991,38 @@ int ensure_fast_layout(cray_ctx* c, cray_scene* s) {
     return CRAY_OK;
 }
 
+// One k_shade launch.  The grid is what the chip holds of THIS instantiation (the occupancy the runtime reports for its registers and
+// LDS, 2 - 4 blocks per CU): the kernel hands its tiles out dynamically, so more blocks than that would only queue behind the resident
+// ones (CRAY_SHADE_BLOCKS_PER_CU > 0 overrides the count for experiments).
+template <uint32_t F, int MODE, class... A>
+void launch_shade(const cray_ctx* c, size_t n_work, hipStream_t st, A... args) {
+    static const int occ = resident_blocks(reinterpret_cast<const void*>(&k_shade<F, MODE>), kBlock, 2);
+    const int per_cu = c->shade_blocks_per_cu > 0 ? c->shade_blocks_per_cu : occ;
+    hipLaunchKernelGGL((k_shade<F, MODE>), dim3(grid_for(c, n_work, per_cu)), dim3(kBlock), 0, st, args...);
+}
+
 template <int I>
 struct ShadeLaunch {
     template <class... A>
-    static void go(int variant, int mode, bool lds_tables, dim3 grid, hipStream_t st, A... args) {
+    static void go(int variant, int mode, bool lds_tables, const cray_ctx* c, size_t n_work, hipStream_t st, A... args) {
         if (mode != 0) {  // the selectable alternatives of the reference (simple integrator, uniform sampler): all-features kernel
-            if (mode == kModeSimple) hipLaunchKernelGGL((k_shade<SF_ALL, kModeSimple>), grid, dim3(kBlock), 0, st, args...);
-            else if (mode == kModeUniform) hipLaunchKernelGGL((k_shade<SF_ALL, kModeUniform>), grid, dim3(kBlock), 0, st, args...);
-            else if (mode == kModeIndependent) hipLaunchKernelGGL((k_shade<SF_ALL, kModeIndependent>), grid, dim3(kBlock), 0, st, args...);
-            else if (mode == (kModeSimple | kModeIndependent)) hipLaunchKernelGGL((k_shade<SF_ALL, kModeSimple | kModeIndependent>), grid, dim3(kBlock), 0, st, args...);
-            else hipLaunchKernelGGL((k_shade<SF_ALL, kModeSimple | kModeUniform>), grid, dim3(kBlock), 0, st, args...);
+            if (mode == kModeSimple) launch_shade<SF_ALL, kModeSimple>(c, n_work, st, args...);
+            else if (mode == kModeUniform) launch_shade<SF_ALL, kModeUniform>(c, n_work, st, args...);
+            else if (mode == kModeIndependent) launch_shade<SF_ALL, kModeIndependent>(c, n_work, st, args...);
+            else if (mode == (kModeSimple | kModeIndependent)) launch_shade<SF_ALL, kModeSimple | kModeIndependent>(c, n_work, st, args...);
+            else launch_shade<SF_ALL, kModeSimple | kModeUniform>(c, n_work, st, args...);
             return;
         }
         if (variant == I) {
-            if (lds_tables) hipLaunchKernelGGL((k_shade<kShadeVariants[I], kModeLdsTables>), grid, dim3(kBlock), 0, st, args...);
-            else hipLaunchKernelGGL((k_shade<kShadeVariants[I], 0>), grid, dim3(kBlock), 0, st, args...);
-        } else ShadeLaunch<I + 1>::go(variant, mode, lds_tables, grid, st, args...);
+            if (lds_tables) launch_shade<kShadeVariants[I], kModeLdsTables>(c, n_work, st, args...);
+            else launch_shade<kShadeVariants[I], 0>(c, n_work, st, args...);
+        } else ShadeLaunch<I + 1>::go(variant, mode, lds_tables, c, n_work, st, args...);
     }
 };
 template <>
 struct ShadeLaunch<kNumShadeVariants> {
     template <class... A>
-    static void go(int, int, bool, dim3, hipStream_t, A...) {}
+    static void go(int, int, bool, const cray_ctx*, size_t, hipStream_t, A...) {}
 };
 
 int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const PassPlan& pp, EventTimer* tm) {
@@ -1019,7 +1037,8 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
     const uint32_t uni_nx = prm.sampler == CRAY_SAMPLER_UNIFORM ? prm.uniform_nx : 0u, uni_ny = prm.sampler == CRAY_SAMPLER_UNIFORM ? prm.uniform_ny : 0u;
     const uint32_t independent = prm.sampler == CRAY_SAMPLER_INDEPENDENT ? 1u : 0u;
     const int mode = (prm.integrator == CRAY_INTEGRATOR_SIMPLE ? kModeSimple : 0) | (uni_nx ? kModeUniform : 0) | (independent ? kModeIndependent : 0);
-    hipLaunchKernelGGL(k_raygen, dim3(grid_for(c, n_paths, 8)), dim3(kBlock), 0, st, d, c->ps, c->pix_list, pp.px0, n_paths, spp_pass, pp.s_lo, prm.seed, uni_nx, uni_ny, independent);
+    static const int occ_raygen = resident_blocks(reinterpret_cast<const void*>(&k_raygen), kBlock, 4);
+    hipLaunchKernelGGL(k_raygen, dim3(grid_for(c, n_paths, 4 * occ_raygen)), dim3(kBlock), 0, st, d, c->ps, c->pix_list, pp.px0, n_paths, spp_pass, pp.s_lo, prm.seed, uni_nx, uni_ny, independent);
     if (tm) { int e = tm->end(); if (e) return e; }
 
     // Launch sequence of a pass.  The shadow rays of bounce b and the path segments of bounce b+1 both depend on
@@ -1044,7 +1063,6 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
         unsigned int* n_next = &ctr->n_active[(b + 1) & 1];
         // an upper bound of the live paths is not known on the host: size the grids for the pass
         const int g_trace = grid_for(c, n_paths, c->trace_blocks_per_cu);  // persistent: 4 blocks x 4 waves per CU at 4 waves/SIMD
-        const int g_shade = grid_for(c, n_paths, c->shade_blocks_per_cu);
         const int g_trace32 = grid_for(c, n_paths, c->trace32_blocks_per_cu);
 
         if (!mixed || b == 0) {
@@ -1058,9 +1076,9 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
 
         HIP_TRY(hipMemsetAsync(n_next, 0, sizeof(unsigned int), st));
         HIP_TRY(hipMemsetAsync(&ctr->n_shadow, 0, sizeof(unsigned int), st));
-        HIP_TRY(hipMemsetAsync(&ctr->trace_head, 0, sizeof(unsigned int), st));
+        HIP_TRY(hipMemsetAsync(&ctr->trace_head, 0, 2 * sizeof(unsigned int), st));   // and shade_head, the word after it
         if (tm) { int e = tm->begin(FAM_SHADE); if (e) return e; }
-        ShadeLaunch<0>::go(s->shade_variant, mode, d.shade_tables_bytes != 0, dim3(g_shade), st, d, ps_b, ps_n, q, nq, n_paths, b, spp_pass, pp.s_lo, q_next, n_next,
+        ShadeLaunch<0>::go(s->shade_variant, mode, d.shade_tables_bytes != 0, c, (size_t)n_paths, st, d, ps_b, ps_n, q, nq, n_paths, b, spp_pass, pp.s_lo, q_next, n_next,
                            c->shadow_queue, &ctr->n_shadow, ctr, trace_all, uni_nx, uni_ny, (const uint32_t*)c->pix_list, pp.px0, prm.seed);
         if (tm) { int e = tm->end(); if (e) return e; }
 
@@ -1097,7 +1115,8 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
     }
     if (tm) { int e = tm->begin(FAM_OTHER); if (e) return e; }
     {
-        const size_t groups = ((size_t)pp.n_pix + 63) / 64, cap = (size_t)c->n_cu * 32;  // one wave per block
+        static const int occ_film = resident_blocks(reinterpret_cast<const void*>(&k_film), 64, 16);
+        const size_t groups = ((size_t)pp.n_pix + 63) / 64, cap = (size_t)c->n_cu * occ_film * 2;  // one wave per block
         const int g_film = (int)(groups < cap ? (groups ? groups : 1) : cap);
         hipLaunchKernelGGL(k_film, dim3(g_film), dim3(64), 0, st, c->ps, c->pix_list, pp.px0, pp.n_pix, spp_pass, pp.s_lo,
                            prm.sample_batch, c->film, ctr);
