@@ -32,6 +32,10 @@ def main(argv=None):
     ap.add_argument('--max-depth', type=int, default=0)
     ap.add_argument('--device', type=int, default=0)
     ap.add_argument('--host-bvh', action='store_true', help='build the BVH on the host (default: on the GPU)')
+    ap.add_argument('--max-paths', type=int, default=16 << 20,
+                    help='paths in flight per pass.  This process renders ONE frame, and the first render of a process pays the driver '
+                         '~20 ms per GiB of path-state pool (364 B per path): 16 Mi paths = 6 GB.  0 = as many as pay in the steady '
+                         'state of a process that renders many frames (bench.py; DESIGN.md 4)')
     args = ap.parse_args(argv)
 
     from . import backend, cry
@@ -47,7 +51,7 @@ def main(argv=None):
     host = backend.HostScene(scene, bvh_ctx=None if args.host_bvh else ctx)  # Bvh::new on the GPU: same tree
     print('Scene constructed in %.1fs' % (time.time() - start), file=sys.stderr)
     dev = ctx.upload(host)
-    film, st = dev.render(seed=args.seed)
+    film, st = dev.render(seed=args.seed, max_paths_in_flight=args.max_paths)
     print('Rendering finished in %.3fs (%.1f Mray/s)' % (st['seconds'], (st['closest_rays'] + st['shadow_rays'] - st['shadow_skipped']) / st['seconds'] / 1e6), file=sys.stderr)
     if args.output.endswith('.npy'):
         np.save(args.output, film)
