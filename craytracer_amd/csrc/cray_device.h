@@ -165,8 +165,9 @@ struct Counters {
     unsigned long long closest_nodes, closest_prims, shadow_nodes, shadow_prims;
     unsigned long long closest_tri, shadow_tri;
     unsigned long long nonfinite, stack_overflow, shadow_skipped, closest_hits;
-    unsigned int n_active[2], n_shadow, trace_head;
-    unsigned int shade_head, pad_head_;   // k_shade's tile dispenser (zeroed before every launch)
+    // The words a bounce zeroes sit between the two queue lengths, so that ONE 16-byte memset does it for either parity:
+    // bounce b zeroes n_active[(b + 1) & 1] (the queue k_shade fills), n_shadow, trace_head and shade_head, and keeps n_active[b & 1].
+    unsigned int n_active0, n_shadow, trace_head, shade_head, n_active1, pad_head_;
     unsigned long long diag[32];  // k_trace lane-occupancy diagnostics (CRAY_TRACE_DIAG builds only)
     // Third level of the traversal stack (LDS -> scratch -> here): entries kStackDepth.. of every lane, in global
     // memory as [entry][global thread].  Allocated by the runtime only after a frame overflowed the first two levels.

@@ -56,7 +56,7 @@ struct cray_ctx {
     int n_cu = 256;
     // idle lanes a wave waits for before it fetches new rays: the coherent camera rays of bounce 0 finish together (late refills
     // cost little and keep neighbouring pixels in one wave), the incoherent later bounces refill earlier (profiles/r02_experiments.md)
-    unsigned int refill_min = 28, refill_min_b0 = 64, refill_min_any = 40;
+    unsigned int refill_min = 28, refill_min_b0 = 64, refill_min_any = 28;
     int trace_blocks_per_cu = 4;
     int trace32_blocks_per_cu = 4;
     int shade_blocks_per_cu = 0;   // 0: the occupancy of the instantiation that runs (launch_shade)
@@ -1058,9 +1058,9 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
         const PathState& ps_b = (b & 1) ? c->ps1 : c->ps;
         const PathState& ps_n = (b & 1) ? c->ps : c->ps1;
         const uint32_t* q = b == 0 ? nullptr : c->queue[b & 1];
-        const unsigned int* nq = b == 0 ? nullptr : &ctr->n_active[b & 1];
+        const unsigned int* nq = b == 0 ? nullptr : ((b & 1) ? &ctr->n_active1 : &ctr->n_active0);
         uint32_t* q_next = c->queue[(b + 1) & 1];
-        unsigned int* n_next = &ctr->n_active[(b + 1) & 1];
+        unsigned int* n_next = ((b + 1) & 1) ? &ctr->n_active1 : &ctr->n_active0;
         // an upper bound of the live paths is not known on the host: size the grids for the pass
         const int g_trace = grid_for(c, n_paths, c->trace_blocks_per_cu);  // persistent: 4 blocks x 4 waves per CU at 4 waves/SIMD
         const int g_trace32 = grid_for(c, n_paths, c->trace32_blocks_per_cu);
@@ -1074,9 +1074,10 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
             if (tm) { int e = tm->end(); if (e) return e; }
         }
 
-        HIP_TRY(hipMemsetAsync(n_next, 0, sizeof(unsigned int), st));
-        HIP_TRY(hipMemsetAsync(&ctr->n_shadow, 0, sizeof(unsigned int), st));
-        HIP_TRY(hipMemsetAsync(&ctr->trace_head, 0, 2 * sizeof(unsigned int), st));   // and shade_head, the word after it
+        // n_next, n_shadow, trace_head and shade_head in one fill: four consecutive words of Counters for either parity (cray_device.h)
+        static_assert(offsetof(Counters, n_shadow) == offsetof(Counters, n_active0) + 4 && offsetof(Counters, n_active1) == offsetof(Counters, n_shadow) + 12,
+                      "the words a bounce zeroes are consecutive");
+        HIP_TRY(hipMemsetAsync(((b + 1) & 1) ? &ctr->n_shadow : &ctr->n_active0, 0, 4 * sizeof(unsigned int), st));
         if (tm) { int e = tm->begin(FAM_SHADE); if (e) return e; }
         ShadeLaunch<0>::go(s->shade_variant, mode, d.shade_tables_bytes != 0, c, (size_t)n_paths, st, d, ps_b, ps_n, q, nq, n_paths, b, spp_pass, pp.s_lo, q_next, n_next,
                            c->shadow_queue, &ctr->n_shadow, ctr, trace_all, uni_nx, uni_ny, (const uint32_t*)c->pix_list, pp.px0, prm.seed);
@@ -1425,11 +1426,11 @@ extern "C" int cray_trace(cray_ctx* c, cray_scene* s, const cray_ray* rays, size
         const unsigned int cnt = (unsigned int)n;
         HIP_TRY(hipMemcpy(c->shadow_queue, iota.data(), n * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(&ctr->n_shadow, &cnt, sizeof(cnt), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(&ctr->n_active[0], &cnt, sizeof(cnt), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(&ctr->n_active0, &cnt, sizeof(cnt), hipMemcpyHostToDevice));
         if (hyb) hipLaunchKernelGGL(k_trace_mixed<true>, dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow,
-                           (const uint32_t*)nullptr, (const unsigned int*)&ctr->n_active[0], ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16));
+                           (const uint32_t*)nullptr, (const unsigned int*)&ctr->n_active0, ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16));
         else hipLaunchKernelGGL(k_trace_mixed<false>, dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow,
-                           (const uint32_t*)nullptr, (const unsigned int*)&ctr->n_active[0], ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16));
+                           (const uint32_t*)nullptr, (const unsigned int*)&ctr->n_active0, ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16));
     } else {
 #define CRAY_TRACE_GO(ANY_, COUNT_, TMAX_)                                                                                       \
     do {                                                                                                                          \

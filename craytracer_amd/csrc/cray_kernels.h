@@ -130,8 +130,8 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
         // positions with ONE atomic and hands them out over several refills, so that most refills do not
         // start with a device-wide atomic round trip.
         const unsigned long long idle = __ballot(!active);
-        // the shadow-ray part of a mixed launch (pixel-ordered rays towards few lights) is more coherent than the path
-        // segments and takes a higher threshold (the high 16 bits of refill_min carry it)
+        // the shadow-ray part of a mixed launch has its own threshold (the high 16 bits of refill_min); since the round-3 compaction
+        // the best value is the path segments' (24-32 of 64 idle lanes, profiles/r03_refill_sweep_final.log), it used to be higher
         const unsigned int refill_now = (MODE == kTraceMixed && res_base >= n_b) ? (refill_min >> 16) : (refill_min & 0xffffu);
         const bool do_refill = (unsigned int)__popcll(idle) >= refill_now && !exhausted;
         // Results of finished rays stay in registers until the wave refills (or drains): the stores then
@@ -699,6 +699,10 @@ __global__ void __launch_bounds__(kBlock) k_make_slots32(const LeafSlot* __restr
 __global__ void __launch_bounds__(kBlock) k_raygen(DevScene sc, PathState ps, const uint32_t* __restrict__ pix_list, uint32_t px0,
                                                    uint32_t n_paths, uint32_t spp_pass, uint32_t s_lo, uint64_t seed, uint32_t uni_nx, uint32_t uni_ny,
                                                    uint32_t independent) {
+    // Sobol set 0 (dimensions 0-3) folded into nibble tables once per block, as in k_shade (cray_shading.h sobol4_lut)
+    __shared__ uint2 l_sob[64];
+    if (threadIdx.x < 64u) sobol_fill_lut(sc.sobol, 0u, threadIdx.x, l_sob);
+    __syncthreads();
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n_paths; p += stride) {
         const uint32_t pix = pix_list[px0 + p / spp_pass];
@@ -715,7 +719,7 @@ __global__ void __launch_bounds__(kBlock) k_raygen(DevScene sc, PathState ps, co
             u[0] = u[2] = ((double)(s % uni_nx) + 0.5) / (double)uni_nx;
             u[1] = u[3] = ((double)(s / uni_nx) + 0.5) / (double)uni_ny;
         } else {
-            sobol4(sc.sobol, s, 0, h, u);  // dims 0,1 film; 2,3 lens (always drawn, craytracer.rs:153-154)
+            sobol4_lut(l_sob, s, 0, h, u);  // dims 0,1 film; 2,3 lens (always drawn, craytracer.rs:153-154)
         }
         ray_t r = camera_ray(sc, u[0], u[1], u[2], u[3], x, y);
         ps.ox[p] = r.o.x; ps.oy[p] = r.o.y; ps.oz[p] = r.o.z;
