@@ -35,7 +35,7 @@ for k, e in res.items():
         # read requests of the 256 L1s to L2 per clock and CU: what a CU fills its L1 with (MI355X_MICROARCH.md: an HBM-bound
         # global_load_dwordx4 stream gets ~10 B per clock and CU).  On gfx950 the counter tallies 128-B requests — like FETCH_SIZE,
         # which reports half the bytes: k_film, a pure stream of 3.2 GB, shows 2.51e7 requests = 3.2 GB at 128 B each
-        # (profiles/r03_v3: FETCH_SIZE x 2 = TCC_MISS x 128 B = TCP_TCC_READ_REQ x 128 B).
+        # (profiles/r03_v4: FETCH_SIZE x 2 = TCC_MISS x 128 B = TCP_TCC_READ_REQ x 128 B).
         e['l1_fill_bytes_per_clk_per_cu'] = round(e['TCP_TCC_READ_REQ_sum'] * 128.0 / 256.0 / (e['GRBM_GUI_ACTIVE'] / 8.0), 2)
     if e.get('SQ_INSTS_VALU') and e.get('GRBM_GUI_ACTIVE'):
         # a wave64 VALU instruction occupies its SIMD for >= 4 cycles (more for the quarter-rate f64 ops): a LOWER bound of the
