@@ -62,6 +62,25 @@ def make_scene(scenes, name):
     return factory(**wl)
 
 
+def cpu_quota():
+    """CPUs the container's cgroup lets this process use (cpu.max quota / period), or None when there is no limit to read."""
+    for path in ('/sys/fs/cgroup/cpu.max',):
+        try:
+            q, per = open(path).read().split()
+            if q != 'max':
+                return round(float(q) / float(per), 2)
+        except Exception:
+            pass
+    try:
+        q = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+        per = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+        if q > 0:
+            return round(q / per, 2)
+    except Exception:
+        pass
+    return None
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -95,12 +114,18 @@ def committed_traffic(workload, lib_hash, launches_per_frame, world=1, precision
             ent = json.load(open(path)).get(workload, {})
         except Exception:
             ent = {}
-    if not ent or world != 1 or precision != 'f64':
+    if world != 1:
+        # the counter passes are of the whole N = 1 frame: a shard's launches move other bytes, so no fraction is quoted for it
+        return None, {'refused': 'N=1 profile only: the committed counter profile is of the unsharded frame; at N > 1 read alg_bytes_rate_GBs and kernel_ms_per_rank'}, ent
+    if not ent or precision != 'f64':
         return None, None, ent
-    provenance = {'file': 'profiles/hbm_traffic.json', 'pmc_csv': ent.get('source'), 'profiled_source_hash': (ent.get('source_hash') or '')[:16],
+    # the key is the hash of the DEVICE-side sources (craytracer_amd/build.py kernel_hash); entries written before round 4 carry
+    # the hash of all sources under 'source_hash' and are compared with whatever the caller passes
+    prof_hash = ent.get('kernel_hash') or ent.get('source_hash')
+    provenance = {'file': 'profiles/hbm_traffic.json', 'pmc_csv': ent.get('source'), 'profiled_source_hash': (prof_hash or '')[:16],
                   'library_source_hash': lib_hash[:16], 'profiled_git': ent.get('git'),
                   'method': 'FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 from separate rocprofv3 --pmc passes (tools/traffic_from_pmc.py)'}
-    if not ent.get('source_hash') or ent.get('source_hash') != lib_hash:
+    if not prof_hash or prof_hash != lib_hash:
         provenance['refused'] = 'the committed counters are of another build of the kernels: re-run tools/profile_round.sh'
         return None, provenance, ent
     # per launch of THIS run: the profiled frame's traversal traffic over this run's launches per frame (the pass plan, hence
@@ -221,7 +246,26 @@ def main():
         stats.append(frame())
     barrier()
     elapsed = time.perf_counter() - t_start
+    local_elapsed = elapsed
     elapsed = float(ctx.allreduce([elapsed], 'max')[0])   # MAX over ranks
+    # N > 1: what the communicator is made of (an all-reduce of 1.0 counts the ranks that really took part; the collective
+    # library's version and file tell librccl from a stand-in), and every rank's own kernel times, so that the line proves
+    # by itself what it ran on and where the slowest rank spent its frame
+    comm = per_rank = None
+    if use_comm:
+        comm = ctx.comm_describe()
+        nf = 6
+        if world * nf <= 64:
+            mine = [0.0] * (world * nf)
+            mine[rank * nf:(rank + 1) * nf] = [local_elapsed / args.steps * 1e3,
+                                               sum(s['trace_closest_ms'] + s['trace_mixed_ms'] + s['trace_any_ms'] for s in stats) / args.steps,
+                                               sum(s['shade_ms'] for s in stats) / args.steps, sum(s['other_ms'] for s in stats) / args.steps,
+                                               float(sum(s['paths'] for s in stats)) / args.steps,
+                                               float(sum(s['closest_rays'] + s['shadow_rays'] - s['shadow_skipped'] for s in stats)) / args.steps]
+            allv = [float(v) for v in ctx.allreduce(mine, 'sum')]
+            per_rank = [{'rank': r, 'wall_ms_per_step': round(allv[r * nf], 3), 'trace_ms': round(allv[r * nf + 1], 3), 'shade_ms': round(allv[r * nf + 2], 3),
+                         'other_ms': round(allv[r * nf + 3], 3), 'paths_per_step': int(allv[r * nf + 4]), 'rays_per_step': int(allv[r * nf + 5])}
+                        for r in range(world)]
     sums = [float(sum(s['closest_rays'] + s['shadow_rays'] - s['shadow_skipped'] for s in stats)),
             float(sum(s['closest_rays'] + s['shadow_rays'] for s in stats)),
             float(sum(s['paths'] for s in stats))]
@@ -282,7 +326,7 @@ def main():
         # HBM bytes the PMC counters saw for these kernels.  Counters need their own rocprofv3 --pmc passes, so this run cannot
         # measure them: they come from the committed profile of THIS build (tools/profile_round.sh -> profiles/hbm_traffic.json),
         # and are refused when the profile is of another build (source hash of the kernels differs from the loaded library's).
-        traffic_frame, provenance, ent = committed_traffic(args.workload, hip_build.loaded_hash(), 1.0, world, args.precision)
+        traffic_frame, provenance, ent = committed_traffic(args.workload, hip_build.loaded_kernel_hash(), 1.0, world, args.precision)
 
         def block(kernel, ms, launches, hbm_per_frame, alg_frame, n_rays):
             per_frame = launches / max(1, args.steps)
@@ -312,6 +356,9 @@ def main():
         else:   # traversal counting frames and max_depth 1 have no mixed launches: the family is the dominant kernel
             roofline = block('k_trace family (k_trace<closest> + k_trace<any>)', fam_ms, fam_launches, traffic_frame, alg_family, traced)
         roofline['bound'] = 'hbm'
+        # `bound` can only say "hbm" or "mfma" (the bench contract); the unit this kernel actually sits on, from the counters
+        # of the profiled build (other_bounds): L1 line fills per CU at the rate a CU can keep in flight
+        roofline['binding_unit'] = 'l1_fill'
         roofline['traffic_provenance'] = provenance
         roofline['bound_note'] = ('HBM is the roofline the north star prices this path against; the counters of the same build say what binds the kernel '
                                   'is per CU: L1 line fills at the rate a CU can keep in flight, texture addresser and f64 VALU issue at ~0.7 each: other_bounds')
@@ -359,25 +406,37 @@ def main():
         tb = time.time()
         oracle_lib.set_libm_mode(1)   # the platform libm's sin/cos, like the reference binary (not the binary128 checker mode)
         orc = oracle_lib.OracleScene(scene)
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+        hw = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+        quota = cpu_quota()
         # A bounded sample that still loads every thread evenly: whole pixels' first samples of the same frame, cut into
-        # square tiles small enough for >= 16 jobs per thread (the reference gets its job count from 64x64 tiles x 8-sample
-        # batches: 4 080 jobs for this frame).  One sample first to size the run, then as many samples as fit ~20 s.
+        # square tiles small enough for >= 16 jobs per thread at the largest thread count tried (the reference gets its job count
+        # from 64x64 tiles x 8-sample batches: 4 080 jobs for this frame).
         tile = 64
-        while tile > 8 and ((W + tile - 1) // tile) * ((H + tile - 1) // tile) < 16 * cores:
+        while tile > 8 and ((W + tile - 1) // tile) * ((H + tile - 1) // tile) < 16 * hw:
             tile //= 2
         jobs = ((W + tile - 1) // tile) * ((H + tile - 1) // tile)
         oracle_lib.set_tile(tile)
-        _, probe = orc.render(seed=0, threads=cores, sample_range=(0, 1))
-        n_s = int(max(1, min(8, wl['spp'], 20.0 / max(probe['seconds'], 1e-3))))
-        _, ost = orc.render(seed=0, threads=cores, sample_range=(0, n_s)) if n_s > 1 else (None, probe)
+        # The box's hardware threads are not necessarily what this process may use (a container's CPU quota throttles whatever
+        # runs beyond it, and SMT siblings share a core's f64 units): one sample at several thread counts first, then the
+        # bounded sample (~20 s) at the count that did best.  `cores` is that count; every count tried is reported.
+        tried = sorted({t for t in (8, 16, 32, 64, 128, hw, int(quota) if quota else 0) if 0 < t <= hw})
+        sweep = []
+        for t in tried:
+            _, pr = orc.render(seed=0, threads=t, sample_range=(0, 1))
+            sweep.append({'threads': t, 'mray_s': round((pr['closest_rays'] + pr['shadow_rays']) / pr['seconds'] / 1e6, 3), 'seconds': round(pr['seconds'], 2)})
+        best = max(sweep, key=lambda e: e['mray_s'])
+        cores = best['threads']
+        n_s = int(max(1, min(8, wl['spp'], 20.0 / max(best['seconds'], 1e-3))))
+        _, ost = orc.render(seed=0, threads=cores, sample_range=(0, n_s))
         oracle_lib.set_tile(0)
         oracle_lib.set_libm_mode(0)
         cpu_rays = ost['closest_rays'] + ost['shadow_rays']
         cpu = {'value': round(cpu_rays / ost['seconds'] / 1e6, 3), 'unit': 'Mray/s', 'cores': cores, 'kind': 'port',
-               'sample': '%d of %d spp of the same %dx%d frame (%d rays, %.1f s) in %d tile jobs of %dx%d pixels = %.1f jobs per thread, dynamically '
-                         'scheduled; C++ restatement of the reference CPU path (-O2, glibc sin/cos), the Rust reference is not buildable here'
-                         % (n_s, wl['spp'], W, H, cpu_rays, ost['seconds'], jobs, tile, tile, jobs / cores)}
+               'per_thread_kray_s': round(cpu_rays / ost['seconds'] / 1e3 / cores, 1),
+               'hardware_threads': hw, 'cpu_quota_cores': quota, 'thread_sweep_one_sample': sweep,
+               'sample': '%d of %d spp of the same %dx%d frame (%d rays, %.1f s) on %d threads — the best of the one-sample sweep over %s threads — in %d tile jobs of '
+                         '%dx%d pixels, dynamically scheduled; C++ restatement of the reference CPU path (-O2, glibc sin/cos), the Rust reference is not buildable here'
+                         % (n_s, wl['spp'], W, H, cpu_rays, ost['seconds'], cores, '/'.join(str(t) for t in tried), jobs, tile, tile)}
         log('cpu baseline: %.2f Mray/s on %d threads (oracle build %.1fs)' % (cpu['value'], cores, time.time() - tb - ost['seconds']))
 
     if rank == 0:
@@ -399,7 +458,7 @@ def main():
                        'rays_per_frame': int(total_rays / args.steps),
                        'reference_queries_per_frame': int(total_queries / args.steps),
                        'build': {'libcray_hip': 'stale' if hip_build.stale() else 'current', 'mode': backend.BUILD_MODE,
-                                 'source_hash': hip_build.loaded_hash()}},
+                                 'source_hash': hip_build.loaded_hash(), 'kernel_hash': hip_build.loaded_kernel_hash()}},
             'roofline': roofline, 'cpu_baseline': cpu,
             'kernel_ms_per_step': {'trace': round(kern[0] / args.steps, 2), 'trace_closest_bounce0': round(kern[2] / args.steps, 2),
                                    'trace_mixed': round(kern[3] / args.steps, 2), 'trace_any_last_bounce': round(kern[4] / args.steps, 2),
@@ -417,6 +476,10 @@ def main():
             diff = fast.astype(np.float64) - exact.astype(np.float64)
             line['fast_mode'] = {'rmse_vs_f64': float(np.sqrt(np.mean(diff ** 2))), 'mean_f64': float(exact.mean()), 'mean_fast': float(fast.mean()),
                                  'pixels_differing': float((fast != exact).any(axis=2).mean())}
+        if comm:
+            line['comm'] = comm
+            line['comm']['launcher_world_size'] = world
+            line['kernel_ms_per_rank'] = per_rank
         if counts:
             line['traversal'] = {k: counts[k] for k in ('closest_rays', 'shadow_rays', 'shadow_skipped', 'closest_nodes', 'closest_prims', 'shadow_nodes', 'shadow_prims')}
         print(json.dumps(line), flush=True)

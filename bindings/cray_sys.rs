@@ -405,6 +405,17 @@ pub struct CrayCommId {
     pub bytes: [u8; 128],
 }
 
+// C: cray_comm_info
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct CrayCommInfo {
+    pub world_size: i32,
+    pub rank: i32,
+    pub ranks_seen: i32,
+    pub rccl_version: i32,
+    pub library: [u8; 256],
+}
+
 pub const CRAY_REDUCE_SUM: c_int = 0;
 pub const CRAY_REDUCE_MAX: c_int = 1;
 pub const CRAY_REDUCE_MIN: c_int = 2;
@@ -475,6 +486,7 @@ extern "C" {
     pub fn cray_comm_world_size(ctx: *const CrayCtx) -> c_int;
     pub fn cray_comm_barrier(ctx: *mut CrayCtx) -> c_int;
     pub fn cray_comm_allreduce_f64(ctx: *mut CrayCtx, values: *mut f64, n: c_int, op: c_int) -> c_int;
+    pub fn cray_comm_describe(ctx: *mut CrayCtx, out: *mut CrayCommInfo) -> c_int;
     pub fn cray_scene_broadcast(ctx: *mut CrayCtx, scene_on_root: *mut CrayScene, root: c_int, out: *mut *mut CrayScene) -> c_int;
     pub fn cray_render_gather(ctx: *mut CrayCtx, scene: *mut CrayScene, params: *const CrayRenderParams, out_rgb: *mut f32, stats: *mut CrayStats) -> c_int;
     pub fn cray_film_gather(ctx: *mut CrayCtx, width: u32, height: u32, tile_width: u32, tile_height: u32,

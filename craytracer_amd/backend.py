@@ -70,6 +70,10 @@ class FlatScene(C.Structure):
 
 
 #: every symbol include/cray.h and include/cray_host.h declare
+class CommInfo(C.Structure):
+    _fields_ = [('world_size', C.c_int32), ('rank', C.c_int32), ('ranks_seen', C.c_int32), ('rccl_version', C.c_int32), ('library', C.c_char * 256)]
+
+
 class BvhBuildStats(C.Structure):
     """cray_bvh_build_stats (include/cray.h)."""
     _fields_ = [('device_seconds', C.c_double), ('total_seconds', C.c_double), ('levels', C.c_uint32),
@@ -84,7 +88,7 @@ ABI_SYMBOLS = ['cray_ctx_create', 'cray_ctx_destroy', 'cray_scene_upload', 'cray
                'cray_cry_tokenize', 'cray_cry_free_tokens', 'cray_cry_parse_value', 'cray_cry_free_string',
                'cray_cry_parse_scene', 'cray_owned_scene_desc', 'cray_owned_scene_warnings', 'cray_owned_scene_free',
                'cray_scene_info', 'cray_comm_unique_id', 'cray_comm_init', 'cray_comm_rank', 'cray_comm_world_size',
-               'cray_comm_barrier', 'cray_comm_allreduce_f64', 'cray_scene_broadcast', 'cray_render_gather',
+               'cray_comm_barrier', 'cray_comm_allreduce_f64', 'cray_comm_describe', 'cray_scene_broadcast', 'cray_render_gather',
                'cray_film_gather', 'cray_film_pack', 'cray_film_unpack', 'cray_measure_stream_read', 'cray_load_image', 'cray_free_image', 'cray_default_image_loader', 'cray_set_sobol_vectors',
                'cray_host_scene_new_resident', 'cray_scene_build_stats', 'cray_tile_pixels', 'cray_preview_checkerboard', 'cray_preview_pixels']
 
@@ -317,6 +321,15 @@ class Context:
         _check(lib().cray_comm_allreduce_f64(self._h, v.ctypes.data, len(v), {'sum': 0, 'max': 1, 'min': 2}[op]),
                'cray_comm_allreduce_f64')
         return v
+
+    def comm_describe(self):
+        """cray_comm_describe: world size and rank of the communicator, the ranks an all-reduce of 1.0 actually counted, the
+        collective library's version and the file it was loaded from.  Collective when there is a communicator."""
+        info = CommInfo()
+        _check(lib().cray_comm_describe(self._h, C.byref(info)), 'cray_comm_describe')
+        path = info.library.decode(errors='replace')
+        return {'world': info.world_size, 'rank': info.rank, 'ranks_seen': info.ranks_seen, 'rccl_version': info.rccl_version,
+                'library': path, 'transport': 'rccl' if os.path.basename(path).startswith('librccl') else ('none' if not path else 'stand-in')}
 
     def broadcast_scene(self, device_scene=None, root=0):
         """cray_scene_broadcast: pass the uploaded DeviceScene on `root`, None elsewhere; returns a DeviceScene."""

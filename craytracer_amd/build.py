@@ -18,7 +18,12 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fP
          '-Wno-unused-function']
 
 
-STAMP = SO + '.srchash'   # hash of flags + sources the .so was built from (travels with it; mtimes do not survive copies)
+STAMP = SO + '.srchash'   # line 1: hash of flags + every source the .so was built from; line 2: hash of the DEVICE side only
+                          # (travels with the .so; mtimes do not survive copies)
+# what the GPU code is compiled from: the one .hip file and the headers it includes.  The counter profile under profiles/ is keyed
+# on THIS hash, so that an edit to a host-side decoder or parser does not orphan the measured HBM traffic of unchanged kernels.
+KERNEL_SOURCES = ['cray_hip.hip', 'cray_math.h', 'cray_device.h', 'cray_shading.h', 'cray_kernels.h', 'cray_bvh_build.h', 'sobol_rev_vectors.h',
+                  '../../include/cray.h', '../../include/cray_scene_desc.h']
 
 
 def source_hash():
@@ -29,21 +34,40 @@ def source_hash():
     return h.hexdigest()
 
 
-def loaded_hash():
-    """Source hash the shipped libcray_hip.so was built from (its stamp); the tree's hash when there is no stamp."""
+def kernel_hash():
+    h = hashlib.sha256(' '.join(FLAGS).encode())
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(CSRC, f), 'rb') as fh:
+            h.update(f.encode() + b'\0' + fh.read())
+    return h.hexdigest()
+
+
+def _stamp_lines():
     try:
         with open(STAMP) as fh:
-            return fh.read().strip()
+            return fh.read().split()
     except OSError:
-        return source_hash()
+        return []
+
+
+def loaded_hash():
+    """Source hash the shipped libcray_hip.so was built from (its stamp); the tree's hash when there is no stamp."""
+    lines = _stamp_lines()
+    return lines[0] if lines else source_hash()
+
+
+def loaded_kernel_hash():
+    """Hash of the device-side sources the shipped library was built from (second line of its stamp)."""
+    lines = _stamp_lines()
+    return lines[1] if len(lines) > 1 else kernel_hash()
 
 
 def stale():
     """True when libcray_hip.so was not built from the sources in the tree (by content, not by mtime)."""
     if not os.path.exists(SO) or not os.path.exists(STAMP):
         return True
-    with open(STAMP) as fh:
-        return fh.read().strip() != source_hash()
+    lines = _stamp_lines()
+    return not lines or lines[0] != source_hash()
 
 
 def build(force=False, verbose=False):
@@ -62,11 +86,11 @@ def build(force=False, verbose=False):
             if verbose:
                 print(' '.join(cmd))
             try:
-                digest = source_hash()
+                digest, kdigest = source_hash(), kernel_hash()
                 subprocess.check_call(cmd, cwd=CSRC)
                 os.replace(tmp, SO)
                 with open(STAMP, 'w') as fh:
-                    fh.write(digest + '\n')
+                    fh.write(digest + '\n' + kdigest + '\n')
             finally:
                 if os.path.exists(tmp):
                     os.remove(tmp)

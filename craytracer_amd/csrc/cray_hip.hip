@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <vector>
 
 #include "cray_bvh_build.h"
@@ -911,12 +912,14 @@ struct PassPlan { uint32_t px0, n_pix, s_lo, s_hi; };
 // a tile; tiles are numbered like generate_tiles (craytracer.rs:32-33): ty outer, tx inner.
 std::vector<uint32_t> rank_pixels(uint32_t W, uint32_t H, const cray_render_params& p) {
     std::vector<uint32_t> pix;
-    uint32_t tiles_x = (W + p.tile_width - 1) / p.tile_width, tiles_y = (H + p.tile_height - 1) / p.tile_height;
-    for (uint32_t t = p.rank; t < tiles_x * tiles_y; t += p.world_size) {
-        uint32_t tx = (t % tiles_x) * p.tile_width, ty = (t / tiles_x) * p.tile_height;
-        uint32_t x1 = tx + p.tile_width < W ? tx + p.tile_width : W, y1 = ty + p.tile_height < H ? ty + p.tile_height : H;
-        for (uint32_t y = ty; y < y1; y++)
-            for (uint32_t x = tx; x < x1; x++) pix.push_back(y * W + x);
+    // 64-bit tile arithmetic: a tile edge near 2^32 must not wrap `W + tw - 1` or `tx + tw` (one tile then covers the film)
+    const uint64_t tw = p.tile_width, th = p.tile_height;
+    const uint64_t tiles_x = (W + tw - 1) / tw, tiles_y = (H + th - 1) / th;
+    for (uint64_t t = p.rank; t < tiles_x * tiles_y; t += p.world_size) {
+        const uint64_t tx = (t % tiles_x) * tw, ty = (t / tiles_x) * th;
+        const uint64_t x1 = tx + tw < W ? tx + tw : W, y1 = ty + th < H ? ty + th : H;
+        for (uint64_t y = ty; y < y1; y++)
+            for (uint64_t x = tx; x < x1; x++) pix.push_back((uint32_t)(y * W + x));
     }
     return pix;
 }
@@ -934,11 +937,24 @@ extern "C" int cray_tile_pixels(uint32_t W, uint32_t H, uint32_t tw, uint32_t th
     cray_render_params p;
     cray_render_params_default(&p);
     p.tile_width = tw; p.tile_height = th; p.rank = rank; p.world_size = world;
-    const std::vector<uint32_t> pix = rank_pixels(W, H, p);
-    *n_pixels = pix.size();
-    if (out) {
+    if (!out) {   // the size query: tile areas summed, no map built
+        const uint64_t tiles_x = ((uint64_t)W + tw - 1) / tw, tiles_y = ((uint64_t)H + th - 1) / th;
+        uint64_t cnt = 0;
+        for (uint64_t t = rank; t < tiles_x * tiles_y; t += world) {
+            const uint64_t tx = (t % tiles_x) * tw, ty = (t / tiles_x) * th;
+            cnt += ((tx + tw < W ? tx + tw : W) - tx) * ((ty + th < H ? ty + th : H) - ty);
+        }
+        *n_pixels = cnt;
+        return CRAY_OK;
+    }
+    try {   // up to 16 GB of indices for a film near 2^32 pixels: nothing may be thrown across the C boundary
+        const std::vector<uint32_t> pix = rank_pixels(W, H, p);
+        *n_pixels = pix.size();
         if (capacity < pix.size()) { set_last_error("cray_tile_pixels: %llu pixels do not fit a buffer of %llu", (unsigned long long)pix.size(), (unsigned long long)capacity); return CRAY_ERR_INVALID; }
         if (!pix.empty()) memcpy(out, pix.data(), pix.size() * sizeof(uint32_t));
+    } catch (const std::exception& ex) {
+        set_last_error("cray_tile_pixels: %s", ex.what());
+        return CRAY_ERR_INVALID;
     }
     return CRAY_OK;
 }
@@ -1204,7 +1220,8 @@ int ensure_buffer(T** buf, size_t* have, size_t want) {
 int ensure_pix_list(cray_ctx* c, uint32_t W, uint32_t H, const cray_render_params& prm) {
     const uint64_t pix_key[6] = {W, H, prm.tile_width, prm.tile_height, prm.rank, prm.world_size};
     if (c->pix_count_valid && memcmp(pix_key, c->pix_key, sizeof(pix_key)) == 0) return CRAY_OK;
-    std::vector<uint32_t> pix = rank_pixels(W, H, prm);
+    std::vector<uint32_t> pix;
+    try { pix = rank_pixels(W, H, prm); } catch (const std::exception& ex) { set_last_error("tile map: %s", ex.what()); return CRAY_ERR_INVALID; }
     c->pix_count_valid = false;
     int e = ensure_buffer(&c->pix_list, &c->pix_capacity, pix.size());
     if (e) return e;
@@ -1241,8 +1258,11 @@ int render_local(cray_ctx* c, cray_scene* s, const cray_render_params* prm, cray
     if (!capacity) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
-        capacity = (size_t)(0.72 * (double)(free_b + c->capacity * kBytesPerPath) / (double)kBytesPerPath);
-        if (capacity < ((size_t)32 << 20)) capacity = (size_t)32 << 20;
+        // a share of what is free, never a floor above it: a GPU this process shares with another tenant (a torch caching
+        // allocator, another ctx or rank on the same device, a smaller-memory part) gets a smaller pool and more passes instead
+        // of a failed allocation.  32 Mi paths only when the runtime cannot say what is free.  Hosts that share a GPU on
+        // purpose set max_paths_in_flight.
+        capacity = free_b ? (size_t)(0.72 * (double)(free_b + c->capacity * kBytesPerPath) / (double)kBytesPerPath) : ((size_t)32 << 20);
     }
     const size_t need = n_pix_rank * (s_end > s_begin ? s_end - s_begin : 0);
     if (need < capacity) capacity = need;
@@ -1250,7 +1270,7 @@ int render_local(cray_ctx* c, cray_scene* s, const cray_render_params* prm, cray
     if (capacity >= ((size_t)1 << 32)) capacity = ((size_t)1 << 32) - 1;
     while ((e = ensure_state(c, capacity))) {
         // the adaptive default asked for more than the allocator gives (fragmentation, another tenant): halve and retry
-        if (prm->max_paths_in_flight || capacity <= ((size_t)32 << 20)) return e;
+        if (prm->max_paths_in_flight || capacity <= (size_t)prm->sample_batch * 4096) return e;
         (void)hipGetLastError();
         capacity /= 2;
     }
@@ -1634,6 +1654,7 @@ struct Rccl {
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;   // optional (reporting only)
 };
 static_assert(sizeof(ncclUniqueId) == CRAY_COMM_ID_BYTES, "cray_comm_id is an ncclUniqueId");
 
@@ -1665,6 +1686,7 @@ Rccl* rccl() {
     api.Recv = (decltype(api.Recv))sym("ncclRecv");
     api.Broadcast = (decltype(api.Broadcast))sym("ncclBroadcast");
     api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
+    api.GetVersion = (decltype(api.GetVersion))dlsym(api.handle, "ncclGetVersion");
     if (!ok) { dlclose(api.handle); api.handle = nullptr; return nullptr; }
     return &api;
 }
@@ -1703,17 +1725,19 @@ int ensure_all_pix(cray_ctx* c, uint32_t W, uint32_t H, uint32_t tw, uint32_t th
     if (c->all_valid && memcmp(key, c->all_key, sizeof(key)) == 0) return CRAY_OK;
     c->all_valid = false;
     std::vector<uint32_t> all;
-    all.reserve((size_t)W * H);
-    c->rank_offset.assign(world + 1, 0);
-    cray_render_params p;
-    cray_render_params_default(&p);
-    p.tile_width = tw; p.tile_height = th; p.world_size = world;
-    for (uint32_t r = 0; r < world; r++) {
-        p.rank = r;
-        const std::vector<uint32_t> mine = rank_pixels(W, H, p);
-        all.insert(all.end(), mine.begin(), mine.end());
-        c->rank_offset[r + 1] = all.size();
-    }
+    try {
+        all.reserve((size_t)W * H);
+        c->rank_offset.assign(world + 1, 0);
+        cray_render_params p;
+        cray_render_params_default(&p);
+        p.tile_width = tw; p.tile_height = th; p.world_size = world;
+        for (uint32_t r = 0; r < world; r++) {
+            p.rank = r;
+            const std::vector<uint32_t> mine = rank_pixels(W, H, p);
+            all.insert(all.end(), mine.begin(), mine.end());
+            c->rank_offset[r + 1] = all.size();
+        }
+    } catch (const std::exception& ex) { set_last_error("tile map: %s", ex.what()); return CRAY_ERR_INVALID; }
     if (all.size() != (size_t)W * H) { set_last_error("internal error: tile lists cover %zu of %zu pixels", all.size(), (size_t)W * H); return CRAY_ERR_INVALID; }
     int e = ensure_buffer(&c->all_pix, &c->all_pix_capacity, all.size());
     if (e) return e;
@@ -1748,22 +1772,33 @@ int gather_tiles(cray_ctx* c, uint32_t W, uint32_t H, uint32_t tw, uint32_t th, 
     Rccl* R = rccl();
     const uint32_t world = (uint32_t)c->comm_world, rank = (uint32_t)c->comm_rank;
     const size_t n_mine = c->pix_count;
+    // An error INSIDE the exchange must not leave this rank's group open or its remaining receives unposted: a receive that was
+    // never posted strands its sender, and an unclosed group poisons the next collective.  So every receive is posted whatever
+    // an earlier one returned, the group is always closed, and the first error is what the call returns.
+    ncclResult_t first = ncclSuccess;
+    const char* what = "";
+#define CRAY_KEEP_FIRST(expr) do { const ncclResult_t r_ = (expr); if (r_ != ncclSuccess && first == ncclSuccess) { first = r_; what = #expr; } } while (0)
     if (rank == 0) {
         const size_t total = (size_t)W * H;
         // rank 0's own tiles go straight to the head of the gathered buffer
         if (n_mine) hipLaunchKernelGGL(k_pack_tiles, dim3(grid_for(c, n_mine * 3, 8)), dim3(kBlock), 0, c->stream, film, c->pix_list, n_mine, div, c->gathered);
-        RCCL_TRY(R, R->GroupStart());
+        CRAY_KEEP_FIRST(R->GroupStart());
         for (uint32_t r = 1; r < world; r++) {
             const size_t cnt = c->rank_offset[r + 1] - c->rank_offset[r];
-            if (cnt) RCCL_TRY(R, R->Recv(c->gathered + c->rank_offset[r] * 3, cnt * 3, ncclFloat, (int)r, c->comm, c->stream));
+            if (cnt) CRAY_KEEP_FIRST(R->Recv(c->gathered + c->rank_offset[r] * 3, cnt * 3, ncclFloat, (int)r, c->comm, c->stream));
         }
-        RCCL_TRY(R, R->GroupEnd());
-        hipLaunchKernelGGL(k_unpack_tiles, dim3(grid_for(c, total * 3, 8)), dim3(kBlock), 0, c->stream, (const float*)c->gathered, (const uint32_t*)c->all_pix, total, dst);
-    } else {
-        if (n_mine) {
-            hipLaunchKernelGGL(k_pack_tiles, dim3(grid_for(c, n_mine * 3, 8)), dim3(kBlock), 0, c->stream, film, c->pix_list, n_mine, div, c->packed);
-            RCCL_TRY(R, R->Send(c->packed, n_mine * 3, ncclFloat, 0, c->comm, c->stream));
-        }
+        CRAY_KEEP_FIRST(R->GroupEnd());
+        if (first == ncclSuccess)
+            hipLaunchKernelGGL(k_unpack_tiles, dim3(grid_for(c, total * 3, 8)), dim3(kBlock), 0, c->stream, (const float*)c->gathered, (const uint32_t*)c->all_pix, total, dst);
+    } else if (n_mine) {
+        hipLaunchKernelGGL(k_pack_tiles, dim3(grid_for(c, n_mine * 3, 8)), dim3(kBlock), 0, c->stream, film, c->pix_list, n_mine, div, c->packed);
+        CRAY_KEEP_FIRST(R->Send(c->packed, n_mine * 3, ncclFloat, 0, c->comm, c->stream));
+    }
+#undef CRAY_KEEP_FIRST
+    if (first != ncclSuccess) {
+        set_last_error("gather of Film tiles: %s failed on rank %u: %s", what, rank, R->GetErrorString(first));
+        (void)hipGetLastError();
+        return CRAY_ERR_HIP;
     }
     HIP_TRY(hipGetLastError());
     return CRAY_OK;
@@ -1888,6 +1923,24 @@ extern "C" int cray_comm_barrier(cray_ctx* c) {
     return cray_comm_allreduce_f64(c, &one, 1, CRAY_REDUCE_SUM);
 }
 
+extern "C" int cray_comm_describe(cray_ctx* c, cray_comm_info* out) {
+    if (!c || !out) { set_last_error("cray_comm_describe: null argument"); return CRAY_ERR_INVALID; }
+    memset(out, 0, sizeof(*out));
+    out->world_size = cray_comm_world_size(c); out->rank = cray_comm_rank(c); out->ranks_seen = 1;
+    if (!c->comm) return CRAY_OK;
+    Rccl* R = rccl();
+    if (!R) return CRAY_ERR_UNSUPPORTED;
+    int v = 0;
+    if (R->GetVersion && R->GetVersion(&v) == ncclSuccess) out->rccl_version = v;
+    Dl_info info;
+    if (dladdr((const void*)R->Send, &info) && info.dli_fname) snprintf(out->library, sizeof(out->library), "%s", info.dli_fname);
+    double one = 1.0;
+    const int e = cray_comm_allreduce_f64(c, &one, 1, CRAY_REDUCE_SUM);
+    if (e) return e;
+    out->ranks_seen = (int32_t)(one + 0.5);
+    return CRAY_OK;
+}
+
 // Every rank passes the return code of the work it did alone (0 or a negative CRAY_ERR_*); every rank gets the worst of
 // them.  Real RCCL has no timeout: a rank that returned early from a collective sequence leaves its peers waiting in
 // ncclRecv / ncclBroadcast for ever, so the ranks agree BEFORE any transfer whose other end might be missing.
@@ -1923,25 +1976,46 @@ extern "C" int cray_scene_broadcast(cray_ctx* c, cray_scene* mine, int root, cra
     else if ((rank == root) != (mine != nullptr)) { set_last_error("cray_scene_broadcast: pass the scene on the root and NULL elsewhere"); bad = CRAY_ERR_INVALID; }
     else if (mine && (mine->ctx != c || mine->allocs.size() != (size_t)kSceneArrays)) { set_last_error("cray_scene_broadcast: scene does not belong to this context"); bad = CRAY_ERR_INVALID; }
     if (world == 1) { if (!bad) *out = mine; return bad; }
+    // From here on every exit goes through an agreement of the ranks: a rank that returned on its own would leave the others
+    // inside ncclBroadcast for ever.  (world > 1 means cray_comm_init succeeded, so the collective library is loaded.)
     Rccl* R = rccl();
     if (!R) return CRAY_ERR_UNSUPPORTED;
-    HIP_TRY(hipSetDevice(c->device));
-    if ((bad = comm_agree(c, bad))) return bad;   // a rank with bad arguments must not leave the others inside ncclBroadcast
+    if (!bad && hipSetDevice(c->device) != hipSuccess) { set_last_error("cray_scene_broadcast: hipSetDevice(%d) failed", c->device); (void)hipGetLastError(); bad = CRAY_ERR_HIP; }
+    {
+        // `root` is part of what must line up: ranks inside ncclBroadcast with different roots wait for each other for ever
+        const double shape[1] = {(double)root};
+        if ((bad = comm_agree(c, bad, shape, 1))) return bad;
+    }
     SceneHeader h;
     memset(&h, 0, sizeof(h));
     if (mine) {
         h.dev = mine->dev; h.n_prims = mine->n_prims; h.magic = 0x43524159u;
         h.features = mine->features; h.shade_variant = mine->shade_variant; h.n_slots = mine->n_slots;
         for (int i = 0; i < kSceneArrays; i++) h.bytes[i] = mine->alloc_bytes[i];
-        HIP_TRY(hipMemcpyAsync(c->comm_scratch, &h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+        if (hipMemcpyAsync(c->comm_scratch, &h, sizeof(h), hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+            // the root still takes part in the header broadcast (a zeroed header: no magic), so that the receivers come back
+            set_last_error("cray_scene_broadcast: the header copy failed on the root");
+            (void)hipGetLastError();
+            (void)hipMemsetAsync(c->comm_scratch, 0, sizeof(h), c->stream);
+            bad = CRAY_ERR_HIP;
+        }
     }
-    RCCL_TRY(R, R->Broadcast(c->comm_scratch, c->comm_scratch, sizeof(h), ncclChar, root, c->comm, c->stream));
-    HIP_TRY(hipMemcpyAsync(&h, c->comm_scratch, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (h.magic != 0x43524159u) { set_last_error("cray_scene_broadcast: bad header from root"); return CRAY_ERR_INVALID; }
+    {
+        const ncclResult_t r = R->Broadcast(c->comm_scratch, c->comm_scratch, sizeof(h), ncclChar, root, c->comm, c->stream);
+        if (r != ncclSuccess && !bad) { set_last_error("cray_scene_broadcast: ncclBroadcast of the header failed: %s", R->GetErrorString(r)); bad = CRAY_ERR_HIP; }
+    }
+    if (!bad) {
+        hipError_t err = hipMemcpyAsync(&h, c->comm_scratch, sizeof(h), hipMemcpyDeviceToHost, c->stream);
+        if (err == hipSuccess) err = hipStreamSynchronize(c->stream);
+        if (err != hipSuccess) { set_last_error("cray_scene_broadcast: reading the header failed: %s", hipGetErrorString(err)); (void)hipGetLastError(); bad = CRAY_ERR_HIP; }
+    }
+    if (!bad && h.magic != 0x43524159u) { set_last_error("cray_scene_broadcast: bad header from root"); bad = CRAY_ERR_INVALID; }
     cray_scene* s = mine;
-    if (!mine) {
-        s = new cray_scene();
+    if (!bad && !mine) {
+        s = new (std::nothrow) cray_scene();
+        if (!s) { set_last_error("cray_scene_broadcast: out of host memory"); bad = CRAY_ERR_HIP; }
+    }
+    if (!bad && !mine) {
         s->ctx = c; s->dev = h.dev; s->n_prims = h.n_prims;
         s->features = h.features; s->shade_variant = h.shade_variant;
         s->n_slots = h.n_slots;
@@ -1953,6 +2027,7 @@ extern "C" int cray_scene_broadcast(cray_ctx* c, cray_scene* mine, int root, cra
             hipError_t err = hipMalloc(&d, h.bytes[i]);
             if (err != hipSuccess) {
                 set_last_error("cray_scene_broadcast: hipMalloc(%llu) failed: %s", (unsigned long long)h.bytes[i], hipGetErrorString(err));
+                (void)hipGetLastError();
                 bad = CRAY_ERR_HIP;
                 break;
             }
@@ -1960,15 +2035,26 @@ extern "C" int cray_scene_broadcast(cray_ctx* c, cray_scene* mine, int root, cra
             *fields[i] = d;
         }
     }
-    // a receiver that could not allocate its copy tells the others before the big transfers start: every rank returns the error
+    // a rank whose header did not arrive or that could not allocate its copy tells the others before the big transfers start:
+    // every rank returns the error
     if ((bad = comm_agree(c, bad))) {
-        if (!mine) cray_scene_free(s);
+        if (!mine && s) cray_scene_free(s);
         return bad;
     }
-    // the big arrays (2.4 GB at 7.2 M triangles) go root HBM -> peer HBM over xGMI, one broadcast per array
-    for (int i = 0; i < kSceneArrays; i++)
-        RCCL_TRY(R, R->Broadcast(s->allocs[i], s->allocs[i], (size_t)h.bytes[i], ncclChar, root, c->comm, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    // the big arrays (2.4 GB at 7.2 M triangles) go root HBM -> peer HBM over xGMI, one broadcast per array.  A broadcast that
+    // fails here does not end the sequence on this rank (the others are inside the same sequence); the first error is returned.
+    ncclResult_t first = ncclSuccess;
+    for (int i = 0; i < kSceneArrays; i++) {
+        const ncclResult_t r = R->Broadcast(s->allocs[i], s->allocs[i], (size_t)h.bytes[i], ncclChar, root, c->comm, c->stream);
+        if (r != ncclSuccess && first == ncclSuccess) first = r;
+    }
+    const hipError_t serr = hipStreamSynchronize(c->stream);
+    if (first != ncclSuccess || serr != hipSuccess) {
+        set_last_error("cray_scene_broadcast: the array transfers failed: %s", first != ncclSuccess ? R->GetErrorString(first) : hipGetErrorString(serr));
+        (void)hipGetLastError();
+        if (!mine) cray_scene_free(s);
+        return CRAY_ERR_HIP;
+    }
     *out = s;
     return CRAY_OK;
 }

@@ -253,6 +253,19 @@ enum { CRAY_REDUCE_SUM = 0, CRAY_REDUCE_MAX = 1, CRAY_REDUCE_MIN = 2 };
 /* In-place all-reduce of n host doubles (timings, ray counts): every rank gets the result. n <= 64. */
 int cray_comm_allreduce_f64(cray_ctx* ctx, double* values, int n, int op);
 
+/* What the communicator is made of, so that a multi-GPU timing can prove what it ran on (bench.py prints it next to every N > 1
+ * figure): `ranks_seen` is an all-reduce (sum) of 1.0 over the communicator — the number of processes that actually took part,
+ * as the transport counts them, not as the launcher's environment claims; `rccl_version` is ncclGetVersion() of the loaded
+ * collective library (0 if it exports none); `library` the path it was loaded from (dladdr of its ncclSend), which tells
+ * librccl.so from a stand-in.  Collective (one all-reduce) when the ctx has a communicator; without one: world 1, ranks_seen 1. */
+typedef struct {
+    int32_t world_size, rank;
+    int32_t ranks_seen;
+    int32_t rccl_version;
+    char library[256];
+} cray_comm_info;
+int cray_comm_describe(cray_ctx* ctx, cray_comm_info* out);
+
 /* C1: replicate a scene that is resident on `root`'s GPU into every other rank's HBM with ncclBroadcast over xGMI
  * (instead of parsing / building / uploading it once per rank).  On `root` pass the uploaded scene, *out == scene;
  * elsewhere pass NULL and receive a new scene (free it with cray_scene_free). Collective. */

@@ -13,6 +13,7 @@
 #include <atomic>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <random>
 #include <vector>
@@ -30,6 +31,21 @@ struct Shared {
     Mailbox box[kMaxRanks][kMaxRanks];   // [src][dst]
 };
 struct Op { bool send; char* buf; size_t bytes, done; int peer; bool started; };
+// Fault injection for the tests of the library's error paths:
+//   MOCK_RCCL_FAIL_SEND=<rank>:<n>   the n-th ncclSend (1-based) the library itself calls on that rank returns an error and sends nothing
+//   MOCK_RCCL_STUCK_MS=<ms>          how long a receive waits for a peer that never sends before it gives up (default 60 000)
+int g_group_depth = 0;      // ncclGroupStart - ncclGroupEnd of this process: must be 0 when the communicator goes away
+int g_sends = 0;            // ncclSend calls made by the library (not the sends inside this file's own collectives)
+uint64_t stuck_limit() {
+    const char* e = getenv("MOCK_RCCL_STUCK_MS");
+    const long ms = e ? atol(e) : 60000;
+    return (uint64_t)(ms > 0 ? ms : 1) * 10;   // polls of 100 us
+}
+bool send_should_fail(int rank) {
+    const char* e = getenv("MOCK_RCCL_FAIL_SEND");
+    int r = -1, n = -1;
+    return e && sscanf(e, "%d:%d", &r, &n) == 2 && r == rank && n == g_sends;
+}
 }  // namespace
 
 struct ncclComm {
@@ -79,7 +95,15 @@ static ncclResult_t run(ncclComm* c, hipStream_t stream) {
             if (!(op.started && op.done == op.bytes)) { all = false; moved |= progress(c, op); }
         }
         if (all) break;
-        if (!moved) { if (++idle > 600000) { fprintf(stderr, "mock_rccl: rank %d stuck for 60 s\n", c->rank); return ncclInternalError; } usleep(100); } else idle = 0;
+        if (!moved) {
+            if (++idle > stuck_limit()) {
+                // give up on what never arrived; the mailboxes are untouched, so the communicator stays usable
+                fprintf(stderr, "mock_rccl: rank %d gave up waiting for a peer\n", c->rank);
+                c->pending.clear();
+                return ncclInternalError;
+            }
+            usleep(100);
+        } else idle = 0;
     }
     c->pending.clear();
     return ncclSuccess;
@@ -117,20 +141,26 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int
 }
 ncclResult_t ncclCommDestroy(ncclComm_t c) {
     if (!c) return ncclSuccess;
+    if (g_group_depth != 0) { fprintf(stderr, "mock_rccl: rank %d left %d group(s) open\n", c->rank, g_group_depth); _exit(5); }
     if (c->sh->attached.fetch_sub(1) == 1) shm_unlink(c->name);
     munmap(c->sh, sizeof(Shared));
     delete c;
     return ncclSuccess;
 }
 const char* ncclGetErrorString(ncclResult_t r) { return r == ncclSuccess ? "no error" : "mock_rccl error"; }
-ncclResult_t ncclGroupStart() { return ncclSuccess; }   // (per-communicator depth is tracked in Send / Recv below)
-ncclResult_t ncclGroupEnd() { return ncclSuccess; }
+ncclResult_t ncclGroupStart() { g_group_depth++; return ncclSuccess; }   // operations still run when they are posted (see below)
+ncclResult_t ncclGroupEnd() { if (g_group_depth <= 0) return ncclInvalidUsage; g_group_depth--; return ncclSuccess; }
+ncclResult_t ncclGetVersion(int* v) { if (v) *v = 0; return ncclSuccess; }   // 0: not a release of the real library
 }
 
 // The library brackets its gather with GroupStart / GroupEnd and posts only receives (rank 0) or one send (the others) inside,
 // so executing each operation when it is posted cannot deadlock; the group calls are accepted and ignored.
 extern "C" {
-ncclResult_t ncclSend(const void* buf, size_t count, ncclDataType_t t, int peer, ncclComm_t c, hipStream_t s) { return post(c, true, buf, count * dtype_size(t), peer, s); }
+ncclResult_t ncclSend(const void* buf, size_t count, ncclDataType_t t, int peer, ncclComm_t c, hipStream_t s) {
+    g_sends++;
+    if (send_should_fail(c->rank)) { fprintf(stderr, "mock_rccl: rank %d: injected failure of ncclSend #%d\n", c->rank, g_sends); return ncclSystemError; }
+    return post(c, true, buf, count * dtype_size(t), peer, s);
+}
 ncclResult_t ncclRecv(void* buf, size_t count, ncclDataType_t t, int peer, ncclComm_t c, hipStream_t s) { return post(c, false, buf, count * dtype_size(t), peer, s); }
 ncclResult_t ncclBroadcast(const void* send, void* recv, size_t count, ncclDataType_t t, int root, ncclComm_t c, hipStream_t s) {
     const size_t bytes = count * dtype_size(t);

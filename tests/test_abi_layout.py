@@ -200,7 +200,7 @@ def test_python_mirrors_match_the_headers(c_layout):
     sizes, fields = c_layout
     from craytracer_amd import backend, scene
     for cls, c_name in ((backend.RenderParams, 'cray_render_params'), (backend.Stats, 'cray_stats'), (backend.FlatScene, 'cray_flat_scene'),
-                        (backend.BvhBuildStats, 'cray_bvh_build_stats')):
+                        (backend.BvhBuildStats, 'cray_bvh_build_stats'), (backend.CommInfo, 'cray_comm_info')):
         size, offs = _ctypes_layout(cls)
         assert size == sizes[c_name], c_name
         assert offs == fields[c_name], c_name

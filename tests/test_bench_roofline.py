@@ -19,7 +19,12 @@ def test_traffic_is_refused_for_another_build(tmp_path):
     assert t is None and 'refused' in prov
     assert bench.committed_traffic('cornell', 'a' * 64, 9.0, path=str(p))[0] is None
     p.write_text(json.dumps({'dragon': {'source_hash': 'a' * 64, 'trace_bytes_per_frame': 900e9}}))
-    assert bench.committed_traffic('dragon', 'a' * 64, 9.0, world=2, path=str(p))[0] is None
+    t, prov, _ = bench.committed_traffic('dragon', 'a' * 64, 9.0, world=2, path=str(p))
+    assert t is None and 'N=1 profile only' in prov['refused']
+    # since round 4 the key is the hash of the device-side sources; it takes precedence over the older all-sources hash
+    p.write_text(json.dumps({'dragon': {'source_hash': 'c' * 64, 'kernel_hash': 'a' * 64, 'trace_bytes_per_frame': 900e9}}))
+    assert bench.committed_traffic('dragon', 'a' * 64, 9.0, path=str(p))[0] == 100e9
+    assert bench.committed_traffic('dragon', 'c' * 64, 9.0, path=str(p))[0] is None
     assert bench.committed_traffic('dragon', 'a' * 64, 9.0, precision='f32', path=str(p))[0] is None
 
 
@@ -29,7 +34,16 @@ def test_the_committed_profile_is_of_the_committed_kernels():
     from craytracer_amd import build
     import os
     path = os.path.join(bench.ROOT, 'profiles', 'hbm_traffic.json')
-    ent = json.load(open(path))['dragon']
-    assert ent.get('source_hash') == build.source_hash(), 're-run tools/profile_round.sh + tools/adopt_profile.sh for the current kernels'
-    t, prov, _ = bench.committed_traffic('dragon', build.source_hash(), 9.0)
-    assert t and 'refused' not in prov
+    for wl in ('dragon', 'cornell', 'staircase'):   # every GPU config of BASELINE.json has its counter profile (round 4)
+        ent = json.load(open(path))[wl]
+        assert ent.get('kernel_hash') == build.kernel_hash(), '%s: re-run tools/profile_round.sh + tools/adopt_profile.sh for the current kernels' % wl
+        t, prov, _ = bench.committed_traffic(wl, build.kernel_hash(), 9.0)
+        assert t and 'refused' not in prov
+
+
+def test_an_edit_to_a_host_side_source_does_not_orphan_the_profile():
+    """The profile key covers what the GPU code is compiled from, not the parsers and decoders of the same library."""
+    from craytracer_amd import build
+    assert 'cray_image.cpp' not in build.KERNEL_SOURCES and 'cray_cry.cpp' not in build.KERNEL_SOURCES and 'cray_host.cpp' not in build.KERNEL_SOURCES
+    assert {'cray_hip.hip', 'cray_kernels.h', 'cray_shading.h', 'cray_math.h', 'cray_device.h', 'cray_bvh_build.h'} <= set(build.KERNEL_SOURCES)
+    assert set(build.KERNEL_SOURCES) <= set(build.SOURCES + build.HEADERS)

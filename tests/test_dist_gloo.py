@@ -4,6 +4,13 @@ the one cray_film_pack packs with and cray_render_gather sends with), gloo stand
 Replaces the merge of the reference's worker threads into one `Mutex<Vec<f32>>` (src/bin/craytracer.rs:245, 271-291,
 182-188): every rank holds the right values on its own tiles only, packs them in the ABI's order, rank 0 receives each
 rank's block at its offset and un-permutes with the ABI's all-ranks map.  The assembled film must be the whole film.
+
+What this CPU test covers of the product is the shard map (cray_tile_pixels) and, with it, the two conventions the device
+code relies on: a rank's block in the gathered buffer starts at the sum of the lower ranks' pixel counts (gather_prepare's
+rank_offset), and the all-ranks map is the concatenation of the per-rank maps in rank order (ensure_all_pix).  The pack /
+receive / unpack steps themselves are restated in torch here; the product's k_pack_tiles / k_unpack_tiles / gather_tiles are
+GPU code and are exercised by tests/test_gpu_comm.py (one GPU, pack + unpack against this same map; 2 and 3 processes through
+the stand-in transport; a send that fails inside the exchange).
 """
 import os
 import socket
@@ -29,6 +36,17 @@ def test_the_abi_s_tile_map_is_the_reference_s():
     p = backend.tile_pixels(130, 70, 1, 3)
     assert p[0] == 64 and p[1] == 65          # tile 1 = (tx = 64, ty = 0): ty outer, tx inner, 64x64 tiles
     assert np.array_equal(backend.tile_pixels(130, 67, 1, 2, tile=(32, 16)), cdist.rank_pixels(130, 67, 1, 2, 32, 16))
+    # a tile edge near 2^32 must not wrap the tile arithmetic: one tile covers the film (round 4: 64-bit tile arithmetic)
+    for big in (2 ** 32 - 1, 2 ** 32 - 64, 2 ** 31):
+        assert np.array_equal(backend.tile_pixels(100, 70, 0, 1, tile=(big, big)), np.arange(7000, dtype=np.uint32)), big
+        assert len(backend.tile_pixels(100, 70, 1, 2, tile=(big, 7))) == 0 + 100 * 7 * 5   # ten row bands of 7, rank 1 owns five
+    # the size query (out = NULL) adds tile areas up without building the map: it must agree with the map
+    import ctypes as C
+    L = backend.lib()
+    for (W, H, tw, th, r, n) in [(1920, 1080, 32, 32, 3, 8), (130, 67, 64, 64, 1, 2), (65, 1, 64, 64, 1, 3), (7, 9, 2, 5, 0, 4)]:
+        cnt = C.c_uint64(0)
+        assert L.cray_tile_pixels(W, H, tw, th, r, n, None, 0, C.byref(cnt)) == 0
+        assert cnt.value == len(cdist.rank_pixels(W, H, r, n, tw, th)), (W, H, tw, th, r, n)
     for bad in ((0, 10, 0, 1), (10, 10, 2, 2), (10, 10, 0, 0)):
         try:
             backend.tile_pixels(*bad)

@@ -185,6 +185,33 @@ def test_a_failing_rank_fails_every_rank_instead_of_hanging_them(tmp_path, world
     assert all(p.returncode == 0 for p in procs), '\n'.join(outs)
 
 
+@pytest.mark.parametrize('world', [2, 3])
+def test_a_send_that_fails_inside_the_exchange_strands_nobody(tmp_path, world):
+    """The status agreement covers what a rank does BEFORE the exchange; this is a failure inside it: rank 1's ncclSend returns an
+    error (injected by the stand-in transport).  gather_tiles must still post every receive and close its ncclGroupStart on rank 0
+    (round 3 returned from inside the group), rank 1 must name the failed call, and the communicator must carry the next frame.
+    Seam: the merge of the reference's workers, src/bin/craytracer.rs:245, 182-188."""
+    backend.lib()
+    so = str(tmp_path / 'libmock_rccl.so')
+    subprocess.check_call(['hipcc', '-std=c++17', '-O2', '-fPIC', '-shared', '-o', so,
+                           os.path.join(ROOT, 'tests', 'mock_rccl', 'mock_rccl.cpp'), '-lrt'], stderr=subprocess.DEVNULL)
+    env = dict(os.environ, CRAY_RCCL_LIB=so, MOCK_RCCL_FAIL_SEND='1:2', MOCK_RCCL_STUCK_MS='3000')
+    worker = os.path.join(ROOT, 'tests', 'mock_rccl', 'worker_sendfail.py')
+    id_path = str(tmp_path / 'comm.id')
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), id_path], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError('a rank was left waiting after a send failed inside the exchange')
+        outs.append(out)
+    assert all(p.returncode == 0 for p in procs), '\n'.join(outs)
+
+
 def test_bench_with_two_ranks_as_the_driver_launches_it(tmp_path):
     """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` — the driver's command for N = 2 — on the one GPU
     of this box, the collective library replaced by the shared-memory stand-in: the id exchange over the rendezvous store,
@@ -204,4 +231,9 @@ def test_bench_with_two_ranks_as_the_driver_launches_it(tmp_path):
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['steps'] == 2 and d['value'] > 0 and d['scaling'] == 'strong'
     assert 'cray_render_gather' in d['config']['parallelism']
+    # the line proves what it ran on: ranks counted by an all-reduce, the collective library named, every rank's kernel times
+    assert d['comm']['world'] == 2 and d['comm']['ranks_seen'] == 2 and d['comm']['transport'] == 'stand-in' and d['comm']['library'].endswith('libmock_rccl.so')
+    assert [r['rank'] for r in d['kernel_ms_per_rank']] == [0, 1] and all(r['trace_ms'] > 0 and r['paths_per_step'] > 0 for r in d['kernel_ms_per_rank'])
+    assert sum(r['paths_per_step'] for r in d['kernel_ms_per_rank']) == 512 * 512 * 64
+    assert d['roofline'] is None or d['roofline'].get('frac') is None
 

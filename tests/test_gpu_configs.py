@@ -1,5 +1,8 @@
-"""BASELINE.json's configs[1], configs[3] and configs[4] at FULL size against the oracle (configs[2] is
-tests/test_gpu_fullsize.py, configs[0] the CPU-only plumbing case of tests/test_golden_films.py).
+"""BASELINE.json's configs[0], configs[1], configs[3] and configs[4] at FULL size against the oracle (configs[2] is
+tests/test_gpu_fullsize.py; tests/test_golden_films.py holds configs[0] at the 48x48x8 size of the committed fixture).
+
+  configs[0]  scenes/simple.cry restated (reference scenes/simple.cry:1-51) at its stated 256x256, 16 spp, depth 4: the whole
+              frame pixel-exact with equal counters (two disks, a glass sphere, an Infinite light and a disk area light).
 
   configs[1]  cornell 512x512, 64 spp, depth 8: the WHOLE 64-spp frame is pixel-exact (the oracle renders it in seconds).
   configs[3]  staircase-class 1920x1080, 256 spp, depth 12 (1.03 M triangles, 10 textures up to 3500x2625): one whole
@@ -27,6 +30,25 @@ def ctx():
     c = backend.Context(0)
     yield c
     c.close()
+
+
+def test_config0_simple_whole_frame_at_its_stated_size_is_pixel_exact(ctx):
+    """BASELINE.json configs[0] is "on CPU reference path (plumbing, no GPU)": the oracle IS that path here, and the GPU film of
+    the same 256x256x16, depth-4 frame must be its film, bit for bit (reference scenes/simple.cry:1-51)."""
+    sc = scenes.simple(256, 256, 16, 4)
+    orc = ol.OracleScene(sc)
+    o, ost = orc.render(seed=0)
+    assert ost['paths'] == 256 * 256 * 16
+    for resident in (False, True):   # the uploaded reference tree and the tree built on the GPU inside the upload
+        dev = ctx.upload(backend.HostScene(sc, resident=resident))
+        g, gst = dev.render(seed=0, count_traversal=True)
+        for k in COUNTERS:
+            assert gst[k] == ost[k], (k, resident)
+        assert gst['nonfinite'] == 0 and gst['stack_overflow'] == 0
+        assert np.array_equal(g, o), resident
+        t, tst = dev.render(seed=0)   # the timed configuration: mixed launches, zero-term shadow rays skipped
+        assert np.array_equal(t, o), resident
+        dev.close()
 
 
 def test_config1_cornell_whole_frame_is_pixel_exact(ctx):

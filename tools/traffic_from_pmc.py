@@ -72,6 +72,7 @@ if __name__ == '__main__':
         for line in open(sys.argv[5]):
             if line.startswith('{'):
                 entry['source_hash'] = json.loads(line)['config']['build'].get('source_hash')
+                entry['kernel_hash'] = json.loads(line)['config']['build'].get('kernel_hash')
     data[workload] = entry
     json.dump(data, open(path, 'w'), indent=1)
     print(json.dumps(entry, indent=1))
