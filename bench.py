@@ -463,7 +463,12 @@ def main():
             'kernel_ms_per_step': {'trace': round(kern[0] / args.steps, 2), 'trace_closest_bounce0': round(kern[2] / args.steps, 2),
                                    'trace_mixed': round(kern[3] / args.steps, 2), 'trace_any_last_bounce': round(kern[4] / args.steps, 2),
                                    'shade': round(kern[5] / args.steps, 2), 'other': round(kern[6] / args.steps, 2),
-                                   'note': "rank 0's share" if world > 1 else 'whole frame'},
+                                   'note': "rank 0's share" if world > 1 else 'whole frame',
+                                   # which records the traversal launches of the timed frames read (cray_stats.trace_records): both give
+                                   # the reference's hits bit for bit; the library keeps per scene and launch kind whichever its first
+                                   # two frames showed to be faster
+                                   'trace_records': {'bounce0': ['f64', 'certified f32 culling', 'pair lines'][stats[-1]['trace_records'] & 15],
+                                                     'other_launches': ['f64', 'certified f32 culling', 'pair lines'][(stats[-1]['trace_records'] >> 4) & 15]}},
         }
         if args.precision != 'f64' and world == 1:
             # how far the fast film is from the exact one: both rendered here, RMSE over RGB (north star: < 1e-4 for the exact path)

@@ -350,7 +350,7 @@ pub struct CrayStats {
     pub trace_closest_launches: u32,
     pub trace_any_launches: u32,
     pub shade_launches: u32,
-    pub pad_: u32,
+    pub trace_records: u32,
     pub trace_mixed_ms: f64,
     pub trace_mixed_launches: u32,
     pub pad2_: u32,

@@ -80,6 +80,14 @@ struct alignas(64) InnerNodeH {
     uint32_t ref0, ref1, axis, pad_;
 };
 static_assert(sizeof(InnerNodeH) == 64, "InnerNodeH is four 16-B loads");
+// ---- pair lines (round 4, CRAY_HYBRID=2): what binds the exact traversal is the number of 128-B LINES a compute unit can fill
+// per clock, and a 64-B record fetched alone still fills a whole line.  Here a node's line also holds the record
+// of ONE of its interior children (`comp`): a lane that descends into that child straight away takes the record from the
+// registers it has just loaded and fetches nothing in its next step.  self.pad_ says which child: 0 none, 1 child 0, 2 child 1.
+struct alignas(128) InnerNodeP {
+    InnerNodeH self, comp;
+};
+static_assert(sizeof(InnerNodeP) == 128, "InnerNodeP is one 128-B line");
 
 struct TriShade {
     double n0[3], n01[3], n02[3];
@@ -114,6 +122,7 @@ struct DevScene {
     const LeafSlot* slots;
     const InnerNode32* inner32;   // fast mode only (built on first use)
     const InnerNodeH* innerh;     // certified f32 culling only (built on first use)
+    const InnerNodeP* innerp;     // certified f32 culling with pair lines (built on first use)
     const LeafSlot32* slots32;
     // primitives
     const cray_prim* prims;

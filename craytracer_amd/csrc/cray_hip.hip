@@ -58,6 +58,7 @@ struct cray_ctx {
     // idle lanes a wave waits for before it fetches new rays: the coherent camera rays of bounce 0 finish together (late refills
     // cost little and keep neighbouring pixels in one wave), the incoherent later bounces refill earlier (profiles/r02_experiments.md)
     unsigned int refill_min = 28, refill_min_b0 = 64, refill_min_any = 28;
+    unsigned int steal = 1;   // work sharing among the lanes of a wave in the drain of the shadow-ray launches (trace_body, STEAL); CRAY_STEAL=0 turns it off
     int trace_blocks_per_cu = 4;
     int trace32_blocks_per_cu = 4;
     int shade_blocks_per_cu = 0;   // 0: the occupancy of the instantiation that runs (launch_shade)
@@ -73,7 +74,10 @@ struct cray_ctx {
     double* deep_key = nullptr;
     unsigned int deep_depth = 0;
     size_t deep_threads = 0;
-    int hybrid = 0;     // certified f32 culling in the exact traversal: opt-in (CRAY_HYBRID=1), same results, not faster as measured
+    int hybrid = -1;    // records the exact traversal reads: 0 f64, 1 certified f32 culling (same results), 2 the same with
+                        // pair lines; -1 (default) = per scene and per launch kind, whichever of 0 / 1 the first two frames show to be
+                        // faster (render_local).  CRAY_HYBRID=0/1/2 pins it.
+    int pair_pick = 0;  // pair lines: which interior child shares its parent's line (0 left first, 1 larger surface area)
     int mix_trace = 1;  // shadow rays of bounce b and segments of bounce b+1 in one launch (CRAY_MIX_TRACE=0 disables)
     int log_queues = 0; // CRAY_LOG_QUEUES=1 (diagnostics): after every bounce, sync and print the queue lengths to stderr
     Counters* counters = nullptr;
@@ -116,6 +120,15 @@ struct cray_scene {
     uint32_t features = SF_ALL;  // what the scene can make k_shade do (cray_shading.h)
     int shade_variant = kNumShadeVariants - 1;
     bool hybrid_ok = false;  // the scene is inside the range the certified f32 culling is proven for (cray_math.h hyb_scene_ok)
+    // Which records the traversal launches of this scene read (0 f64, 1 certified f32 culling, 2 pair lines): the bounce-0 launch
+    // (coherent camera rays) and the others separately.  Both kinds of records give the reference's hits bit for bit, so the
+    // choice is a matter of speed only and it depends on the scene: on the dragon the f32 culling is 3-5 % faster in both
+    // kinds, in the Cornell box (axis-aligned boxes: most decisions need the exact retake) 35 % slower, in the staircase
+    // interior 12 % faster for camera rays and 4 % slower for the rest.  With ctx->hybrid = -1 the first frame of a scene that
+    // is big enough to time runs on f64 records, the second on f32 culling, and the faster one per kind is kept.
+    int use_b0 = 0, use_rest = 0;
+    int tune_stage = 0;            // 0: nothing measured, 1: f64 measured, 2: both measured, choice made
+    double tune_ns[2][2] = {{0.0, 0.0}, {0.0, 0.0}};   // [variant][kind]: ns per ray of the bounce-0 launch / of the other launches
 };
 
 namespace {
@@ -325,11 +338,13 @@ extern "C" int cray_ctx_create(int device_id, void* stream, cray_ctx** out) {
         return v < lo ? lo : (v > hi ? hi : v);
     };
     c->mix_trace = env_int("CRAY_MIX_TRACE", 0, 1, c->mix_trace);
-    c->hybrid = env_int("CRAY_HYBRID", 0, 1, c->hybrid);
+    c->hybrid = env_int("CRAY_HYBRID", -1, 2, c->hybrid);
+    c->pair_pick = env_int("CRAY_PAIR_PICK", 0, 1, c->pair_pick);
     c->log_queues = env_int("CRAY_LOG_QUEUES", 0, 1, 0);
     c->refill_min = (unsigned int)env_int("CRAY_REFILL_MIN", 1, 64, (int)c->refill_min);
     c->refill_min_b0 = (unsigned int)env_int("CRAY_REFILL_MIN_B0", 1, 64, (int)c->refill_min_b0);
     c->refill_min_any = (unsigned int)env_int("CRAY_REFILL_MIN_ANY", 1, 64, (int)c->refill_min_any);
+    c->steal = (unsigned int)env_int("CRAY_STEAL", 0, 1, (int)c->steal);
     c->trace_blocks_per_cu = env_int("CRAY_TRACE_BLOCKS_PER_CU", 1, 16, c->trace_blocks_per_cu);
     c->shade_blocks_per_cu = env_int("CRAY_SHADE_BLOCKS_PER_CU", 0, 64, c->shade_blocks_per_cu);
     c->trace32_blocks_per_cu = env_int("CRAY_TRACE32_BLOCKS_PER_CU", 1, 16, c->trace32_blocks_per_cu);
@@ -976,11 +991,23 @@ int ensure_inner32(cray_ctx* c, cray_scene* s) {
     return CRAY_OK;
 }
 // Exact traversal with certified f32 culling: decided per scene (range of the bounds), records derived on first use.
-int ensure_hybrid(cray_ctx* c, cray_scene* s) {
-    s->hybrid_ok = s->dev.bounds_in_div_range && hyb_scene_ok(s->dev.root_lo, s->dev.root_hi);
-    if (!c->hybrid || !s->hybrid_ok || s->dev.innerh) return CRAY_OK;
-    InnerNodeH* ih = nullptr;
+int ensure_hybrid(cray_ctx* c, cray_scene* s, int level) {
+    if (level <= 0 || !s->hybrid_ok) return CRAY_OK;
     const uint32_t n_inner = s->dev.n_inner ? s->dev.n_inner : 1u;
+    if (level == 2) {   // pair lines: a node's record + the record of one interior child in one 128-B line
+        if (s->dev.innerp) return CRAY_OK;
+        InnerNodeP* ip = nullptr;
+        HIP_TRY(hipMalloc((void**)&ip, (size_t)n_inner * sizeof(InnerNodeP)));
+        s->extra_allocs.push_back(ip);
+        hipLaunchKernelGGL(k_make_innerp, dim3((n_inner + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, s->dev.inner, n_inner, ip, (uint32_t)c->pair_pick);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipGetLastError());
+        s->bytes += (size_t)n_inner * sizeof(InnerNodeP);
+        s->dev.innerp = ip;
+        return CRAY_OK;
+    }
+    if (s->dev.innerh) return CRAY_OK;
+    InnerNodeH* ih = nullptr;
     HIP_TRY(hipMalloc((void**)&ih, (size_t)n_inner * sizeof(InnerNodeH)));
     s->extra_allocs.push_back(ih);
     hipLaunchKernelGGL(k_make_innerh, dim3((n_inner + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, s->dev.inner, n_inner, ih);
@@ -989,6 +1016,29 @@ int ensure_hybrid(cray_ctx* c, cray_scene* s) {
     s->bytes += (size_t)n_inner * sizeof(InnerNodeH);
     s->dev.innerh = ih;
     return CRAY_OK;
+}
+// The records this call's traversal launches read.  Pinned by CRAY_HYBRID / ctx->hybrid >= 0; otherwise chosen per scene from
+// the first two frames that are big enough to time (cray_scene::use_b0).  `measuring` (out): this frame is one of those two.
+int choose_trace_records(cray_ctx* c, cray_scene* s, bool counting, size_t n_paths, int* measuring) {
+    *measuring = -1;
+    s->hybrid_ok = s->dev.bounds_in_div_range && hyb_scene_ok(s->dev.root_lo, s->dev.root_hi);
+    if (!s->hybrid_ok) { s->use_b0 = s->use_rest = 0; return CRAY_OK; }
+    if (c->hybrid >= 0) {
+        // the counting launches of a pair-line context run the plain f64 kernels (equal counters by construction)
+        s->use_b0 = s->use_rest = (c->hybrid == 2 && counting) ? 0 : c->hybrid;
+    } else if (counting) {
+        s->use_b0 = s->use_rest = 0;
+    } else if (s->tune_stage >= 2) {
+        // chosen
+    } else if (n_paths < ((size_t)1 << 21)) {
+        s->use_b0 = s->use_rest = 0;   // too small to tell anything: f64 records, nothing measured
+    } else {
+        s->use_b0 = s->use_rest = s->tune_stage;   // frame 1 of the scene: f64 records; frame 2: certified f32 culling
+        *measuring = s->tune_stage;
+    }
+    int e = ensure_hybrid(c, s, s->use_b0);
+    if (!e) e = ensure_hybrid(c, s, s->use_rest);
+    return e;
 }
 // The f32 triangle records of the fast mode, derived the first time a fast frame is asked for.
 int ensure_fast_layout(cray_ctx* c, cray_scene* s) {
@@ -1062,11 +1112,13 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
     // kind keeps its own launch so that the counters stay per kind.
     const bool mixed = !count && c->mix_trace;
     const bool fast = prm.precision == CRAY_PRECISION_F32_TRAVERSAL;   // check_render_args refuses it together with counting
-    const bool hyb = s->dev.innerh != nullptr && c->hybrid && s->hybrid_ok;   // certified f32 culling (cray_math.h hyb_key): same results
-#define CRAY_LAUNCH_TRACE(ANY_, COUNT_, ...)                                                                                   \
+    // which records the launches read (cray_scene::use_b0 / use_rest): 0 f64, 1 certified f32 culling (cray_math.h hyb_key),
+    // 2 the same with pair lines (timed launches only).  Same results whichever.
+#define CRAY_LAUNCH_TRACE(V_, ANY_, COUNT_, ...)                                                                               \
     do {                                                                                                                        \
-        if (hyb) hipLaunchKernelGGL((k_trace<ANY_, COUNT_, true>), dim3(g_trace), dim3(kBlock), 0, st, __VA_ARGS__);              \
-        else hipLaunchKernelGGL((k_trace<ANY_, COUNT_, false>), dim3(g_trace), dim3(kBlock), 0, st, __VA_ARGS__);                 \
+        if ((V_) == 2 && !COUNT_) hipLaunchKernelGGL((k_trace<ANY_, false, 2>), dim3(g_trace), dim3(kBlock), 0, st, __VA_ARGS__); \
+        else if ((V_) == 1) hipLaunchKernelGGL((k_trace<ANY_, COUNT_, 1>), dim3(g_trace), dim3(kBlock), 0, st, __VA_ARGS__);      \
+        else hipLaunchKernelGGL((k_trace<ANY_, COUNT_, 0>), dim3(g_trace), dim3(kBlock), 0, st, __VA_ARGS__);                     \
     } while (0)
     const unsigned int trace_all = prm.count_traversal == 1 ? 1u : 0u;  // 2 = count, but keep skipping zero-term shadow rays
     for (uint32_t b = 0; b < d.max_depth; b++) {
@@ -1084,9 +1136,10 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
         if (!mixed || b == 0) {
             HIP_TRY(hipMemsetAsync(&ctr->trace_head, 0, sizeof(unsigned int), st));
             if (tm) { int e = tm->begin(FAM_CLOSEST); if (e) return e; }
-            if (count) CRAY_LAUNCH_TRACE(false, true, d, ps_b, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
+            const int v_closest = b == 0 ? s->use_b0 : s->use_rest;
+            if (count) CRAY_LAUNCH_TRACE(v_closest, false, true, d, ps_b, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
             else if (fast) hipLaunchKernelGGL((k_trace32<kTraceClosest>), dim3(g_trace32), dim3(kBlock), 0, st, d, ps_b, q, nq, n_paths, (const uint32_t*)nullptr, (const unsigned int*)nullptr, ctr, &ctr->trace_head, b == 0 ? c->refill_min_b0 : c->refill_min, b == 0 ? 1u : 0u);
-            else CRAY_LAUNCH_TRACE(false, false, d, ps_b, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, b == 0 ? c->refill_min_b0 : c->refill_min);
+            else CRAY_LAUNCH_TRACE(v_closest, false, false, d, ps_b, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, b == 0 ? c->refill_min_b0 : c->refill_min);
             if (tm) { int e = tm->end(); if (e) return e; }
         }
 
@@ -1103,17 +1156,19 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
             if (tm) { int e = tm->begin(FAM_MIXED); if (e) return e; }
             if (fast) hipLaunchKernelGGL((k_trace32<kTraceMixed>), dim3(g_trace32), dim3(kBlock), 0, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, 0u,
                                          (const uint32_t*)q_next, (const unsigned int*)n_next, ctr, &ctr->trace_head, c->refill_min, 0u);
-            else if (hyb) hipLaunchKernelGGL(k_trace_mixed<true>, dim3(g_trace), dim3(kBlock), 0, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow,
-                               (const uint32_t*)q_next, (const unsigned int*)n_next, ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16));
-            else hipLaunchKernelGGL(k_trace_mixed<false>, dim3(g_trace), dim3(kBlock), 0, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow,
-                               (const uint32_t*)q_next, (const unsigned int*)n_next, ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16));
+            else if (s->use_rest == 2) hipLaunchKernelGGL(k_trace_mixed<2>, dim3(g_trace), dim3(kBlock), 0, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow,
+                               (const uint32_t*)q_next, (const unsigned int*)n_next, ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16) | (c->steal ? 0x8000u : 0u));
+            else if (s->use_rest == 1) hipLaunchKernelGGL(k_trace_mixed<1>, dim3(g_trace), dim3(kBlock), 0, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow,
+                               (const uint32_t*)q_next, (const unsigned int*)n_next, ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16) | (c->steal ? 0x8000u : 0u));
+            else hipLaunchKernelGGL(k_trace_mixed<0>, dim3(g_trace), dim3(kBlock), 0, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow,
+                               (const uint32_t*)q_next, (const unsigned int*)n_next, ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16) | (c->steal ? 0x8000u : 0u));
             if (tm) { int e = tm->end(); if (e) return e; }
         } else {
             if (tm) { int e = tm->begin(FAM_ANY); if (e) return e; }
-            if (count) CRAY_LAUNCH_TRACE(true, true, d, ps_n, c->shadow_queue, &ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
+            if (count) CRAY_LAUNCH_TRACE(s->use_rest, true, true, d, ps_n, c->shadow_queue, &ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
             else if (fast) hipLaunchKernelGGL((k_trace32<kTraceAny>), dim3(g_trace32), dim3(kBlock), 0, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, 0u,
                                               (const uint32_t*)nullptr, (const unsigned int*)nullptr, ctr, &ctr->trace_head, c->refill_min, 0u);
-            else CRAY_LAUNCH_TRACE(true, false, d, ps_n, c->shadow_queue, &ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min_any);
+            else CRAY_LAUNCH_TRACE(s->use_rest, true, false, d, ps_n, c->shadow_queue, &ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min_any | (c->steal ? 0x8000u : 0u));
             if (tm) { int e = tm->end(); if (e) return e; }
         }
         if (c->log_queues) {   // diagnostics only: a host round trip per bounce
@@ -1245,8 +1300,10 @@ int render_local(cray_ctx* c, cray_scene* s, const cray_render_params* prm, cray
     int e;
     if ((e = ensure_pix_list(c, W, H, *prm))) return e;
     if (prm->precision == CRAY_PRECISION_F32_TRAVERSAL && (e = ensure_fast_layout(c, s))) return e;
-    if ((e = ensure_hybrid(c, s))) return e;
     const size_t n_pix_rank = c->pix_count;
+    int measuring = -1;   // >= 0: this frame's traversal times decide which records the scene's later frames read
+    if ((e = choose_trace_records(c, s, prm->count_traversal != 0 || prm->precision != CRAY_PRECISION_F64,
+                                  n_pix_rank * (size_t)(s_end > s_begin ? s_end - s_begin : 0), &measuring))) return e;
     const size_t film_floats = (size_t)W * H * 3;
     if ((e = ensure_buffer(&c->film, &c->film_floats, film_floats))) return e;
     // Paths in flight per pass.  Fewer, larger passes are faster (every launch of a pass ends in a drain phase, and late bounces
@@ -1280,19 +1337,35 @@ int render_local(cray_ctx* c, cray_scene* s, const cray_render_params* prm, cray
         HIP_TRY(hipMemsetAsync(c->film, 0, film_floats * sizeof(float), c->stream));
         if ((e = reset_counters(c))) return e;
         EventTimer timer(c);
-        EventTimer* tm = stats ? &timer : nullptr;
+        EventTimer* tm = (stats || measuring >= 0) ? &timer : nullptr;
         for (const PassPlan& pp : passes)
             if ((e = run_pass(c, s, *prm, pp, tm))) return e;
         Counters h;
         HIP_TRY(hipMemcpyAsync(&h, c->counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
         hipError_t err = hipStreamSynchronize(c->stream);
         if (err != hipSuccess) { set_last_error("render failed: %s", hipGetErrorString(err)); return CRAY_ERR_HIP; }
+        double ms[FAM_COUNT]; uint32_t launches[FAM_COUNT];
+        if (tm && (e = timer.collect(ms, launches))) return e;
+        if (measuring >= 0 && !h.stack_overflow) {
+            // ns per ray of the bounce-0 launch (one camera ray per path) and of all the other traversal launches
+            const double r0 = (double)need, r1 = (double)(h.closest_rays + h.shadow_rays) - (double)h.shadow_skipped - r0;
+            s->tune_ns[measuring][0] = ms[FAM_CLOSEST] * 1e6 / (r0 > 0 ? r0 : 1.0);
+            s->tune_ns[measuring][1] = (ms[FAM_MIXED] + ms[FAM_ANY]) * 1e6 / (r1 > 0 ? r1 : 1.0);
+            s->tune_stage = measuring + 1;
+            if (s->tune_stage == 2) {
+                // the f32 culling has to win by more than the noise of one frame (1 %) to replace the plain records
+                s->use_b0 = s->tune_ns[1][0] < 0.99 * s->tune_ns[0][0] ? 1 : 0;
+                s->use_rest = (r1 > 0 && s->tune_ns[1][1] < 0.99 * s->tune_ns[0][1]) ? 1 : 0;
+                if (c->log_queues)
+                    fprintf(stderr, "[cray] traversal records chosen for this scene: bounce 0 %s (%.3f vs %.3f ns/ray), other launches %s (%.3f vs %.3f ns/ray)\n",
+                            s->use_b0 ? "f32 culling" : "f64", s->tune_ns[1][0], s->tune_ns[0][0], s->use_rest ? "f32 culling" : "f64", s->tune_ns[1][1], s->tune_ns[0][1]);
+            }
+        }
         if (stats) {
             memset(stats, 0, sizeof(*stats));
             fill_stats(h, stats);
             stats->paths = need;
-            double ms[FAM_COUNT]; uint32_t launches[FAM_COUNT];
-            if ((e = timer.collect(ms, launches))) return e;
+            stats->trace_records = (uint32_t)(measuring >= 0 ? measuring * 0x11 : ((prm->count_traversal || prm->precision != CRAY_PRECISION_F64) ? 0 : (s->use_b0 | (s->use_rest << 4))));
             stats->trace_mixed_ms = ms[FAM_MIXED]; stats->trace_mixed_launches = launches[FAM_MIXED];
             stats->trace_closest_ms = ms[FAM_CLOSEST]; stats->trace_any_ms = ms[FAM_ANY];
             stats->shade_ms = ms[FAM_SHADE]; stats->other_ms = ms[FAM_OTHER];
@@ -1436,8 +1509,11 @@ extern "C" int cray_trace(cray_ctx* c, cray_scene* s, const cray_ray* rays, size
     }
     const int g = grid_for(c, n, 8);
     Counters* ctr = c->counters;
-    if ((e = ensure_hybrid(c, s))) return e;
-    const bool hyb = s->dev.innerh != nullptr && c->hybrid && s->hybrid_ok;
+    // the per-ray hook reads the records the context is pinned to (CRAY_HYBRID); a context that chooses per scene reads f64 here
+    s->hybrid_ok = s->dev.bounds_in_div_range && hyb_scene_ok(s->dev.root_lo, s->dev.root_hi);
+    const int level = (c->hybrid > 0 && s->hybrid_ok) ? c->hybrid : 0;
+    if ((e = ensure_hybrid(c, s, level))) return e;
+    const bool hyb = level == 1, hyb2 = level == 2;
     if (mixed) {
         // k_trace_mixed as the frame loop launches it: positions [0, n) of the virtual queue are the shadow rays of paths
         // 0..n-1 (an identity queue), positions [n, 2n) the path segments of the same paths (tmax = +inf, like Ray::new)
@@ -1447,15 +1523,18 @@ extern "C" int cray_trace(cray_ctx* c, cray_scene* s, const cray_ray* rays, size
         HIP_TRY(hipMemcpy(c->shadow_queue, iota.data(), n * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(&ctr->n_shadow, &cnt, sizeof(cnt), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(&ctr->n_active0, &cnt, sizeof(cnt), hipMemcpyHostToDevice));
-        if (hyb) hipLaunchKernelGGL(k_trace_mixed<true>, dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow,
-                           (const uint32_t*)nullptr, (const unsigned int*)&ctr->n_active0, ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16));
-        else hipLaunchKernelGGL(k_trace_mixed<false>, dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow,
-                           (const uint32_t*)nullptr, (const unsigned int*)&ctr->n_active0, ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16));
+        if (hyb2) hipLaunchKernelGGL(k_trace_mixed<2>, dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow,
+                           (const uint32_t*)nullptr, (const unsigned int*)&ctr->n_active0, ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16) | (c->steal ? 0x8000u : 0u));
+        else if (hyb) hipLaunchKernelGGL(k_trace_mixed<1>, dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow,
+                           (const uint32_t*)nullptr, (const unsigned int*)&ctr->n_active0, ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16) | (c->steal ? 0x8000u : 0u));
+        else hipLaunchKernelGGL(k_trace_mixed<0>, dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow,
+                           (const uint32_t*)nullptr, (const unsigned int*)&ctr->n_active0, ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16) | (c->steal ? 0x8000u : 0u));
     } else {
 #define CRAY_TRACE_GO(ANY_, COUNT_, TMAX_)                                                                                       \
     do {                                                                                                                          \
-        if (hyb) hipLaunchKernelGGL((k_trace<ANY_, COUNT_, true>), dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)nullptr, (const unsigned int*)nullptr, (uint32_t)n, TMAX_, ctr, &ctr->trace_head, c->refill_min); \
-        else hipLaunchKernelGGL((k_trace<ANY_, COUNT_, false>), dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)nullptr, (const unsigned int*)nullptr, (uint32_t)n, TMAX_, ctr, &ctr->trace_head, c->refill_min); \
+        if (hyb2 && !COUNT_) hipLaunchKernelGGL((k_trace<ANY_, false, 2>), dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)nullptr, (const unsigned int*)nullptr, (uint32_t)n, TMAX_, ctr, &ctr->trace_head, c->refill_min | (c->steal ? 0x8000u : 0u)); \
+        else if (hyb) hipLaunchKernelGGL((k_trace<ANY_, COUNT_, 1>), dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)nullptr, (const unsigned int*)nullptr, (uint32_t)n, TMAX_, ctr, &ctr->trace_head, c->refill_min | (c->steal ? 0x8000u : 0u)); \
+        else hipLaunchKernelGGL((k_trace<ANY_, COUNT_, 0>), dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)nullptr, (const unsigned int*)nullptr, (uint32_t)n, TMAX_, ctr, &ctr->trace_head, c->refill_min | (c->steal ? 0x8000u : 0u)); \
     } while (0)
         // closest hit with caller-supplied tmax: rays whose tmax is finite go through the same kernel via stmax
         if (mode == CRAY_TRACE_ANY) CRAY_TRACE_GO(true, true, (const double*)nullptr);
@@ -2019,7 +2098,7 @@ extern "C" int cray_scene_broadcast(cray_ctx* c, cray_scene* mine, int root, cra
         s->ctx = c; s->dev = h.dev; s->n_prims = h.n_prims;
         s->features = h.features; s->shade_variant = h.shade_variant;
         s->n_slots = h.n_slots;
-        s->dev.inner32 = nullptr; s->dev.slots32 = nullptr; s->dev.innerh = nullptr;   // the fast-mode records are derived per rank on first use
+        s->dev.inner32 = nullptr; s->dev.slots32 = nullptr; s->dev.innerh = nullptr; s->dev.innerp = nullptr;   // the fast-mode records are derived per rank on first use
         const void** fields[kSceneArrays];
         scene_arrays(s->dev, fields);
         for (int i = 0; i < kSceneArrays && !bad; i++) {

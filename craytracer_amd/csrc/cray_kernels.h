@@ -40,6 +40,12 @@ constexpr int kBlock = 256;
 #ifndef CRAY_TRACE_WAVES
 #define CRAY_TRACE_WAVES 4
 #endif
+// CRAY_TRACE_EU(min, max): pin the waves per SIMD the register allocator plans for (experiments; default: launch bounds only)
+#ifdef CRAY_TRACE_EU_MAX
+#define CRAY_TRACE_EU __attribute__((amdgpu_waves_per_eu(CRAY_TRACE_WAVES, CRAY_TRACE_EU_MAX)))
+#else
+#define CRAY_TRACE_EU
+#endif
 //  MODE 2 (mixed): ONE launch traces the path segments of bounce b+1 (positions [0, n_closest) of a virtual queue) and
 //  the shadow rays of bounce b (the rest).  The two depend only on k_shade of bounce b, not on each other
 //  (the shadow rays add to L, the segments write hit records), and together they have one drain phase instead
@@ -54,12 +60,30 @@ enum { kTraceClosest = 0, kTraceAny = 1, kTraceMixed = 2 };
 #endif
 //  HYB        : certified f32 culling (cray_math.h hyb_key): interior nodes are read as 64-B f32 records, every decision the f32
 //               enclosure cannot certify is retaken from the f64 record in a RESOLVE step of the lane.  Same hits, same counters.
-template <int MODE, bool COUNT, bool HYB>
+//  HYB = 2    : the same with pair lines (InnerNodeP): the record of the child a lane descends into may already be in its registers.
+template <int MODE, bool COUNT, int HYB>
 __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& ps, const uint32_t* __restrict__ queue, const uint32_t n_first,
                                            const uint32_t* __restrict__ queue_b, const uint32_t n_b, const double* __restrict__ closest_tmax,
                                            Counters* ctr, unsigned int* work_head, unsigned int refill_min) {
     static_assert(!(COUNT && MODE == kTraceMixed), "traversal counting uses the separate launches");
     constexpr bool ANY = MODE == kTraceAny;   // for the counting code, which never runs mixed
+    // ---- the drain of a launch: idle lanes take over parts of the shadow rays that are still running (round 4).
+    // Once the queue is empty a launch lasts as long as its longest rays: 300-400 dependent node visits on a chip that empties,
+    // ~0.7 ms per launch whatever its size (3 % of the whole frame, a fifth of an eighth of it).  An any-hit query never changes
+    // ray.tmax (bvh.rs:106-147: `intersects` borrows the ray immutably), so the nodes it visits form a fixed tree — every node
+    // all of whose ancestors pass `key < tmax` — and its answer is the OR over the primitives in the leaves of that tree:
+    // independent of the order, hence of WHO walks which part.  A deferred child on a lane's stack is the root of a part nobody
+    // has started; an idle lane of the same wave takes the BOTTOM entry (the shallowest deferral: the largest part) together
+    // with a copy of the ray and walks it with its own stack.  The workers of one ray share a counter and an "occluded" flag in
+    // LDS; a hit anywhere stops them all, and the worker that finishes last adds the NEE term when nobody hit
+    // (path_integrator.rs:141-163).  Closest-hit queries are NOT split: their tmax shrinks with every accepted hit, and where the
+    // reference's slab test and triangle test disagree in the last bit (scenes/rounding-error.cry) the result depends on the order.
+    // Not used by the counting builds (the reference's early exit defines their counters) nor with HYB.
+    // Built into the any-hit launch only (the last bounce of a pass): inside the loop of the mixed launches the same code cost
+    // 9 % of the bulk (two spilled registers, compares in every iteration) for -0.2 ms of tail per launch — their tails are
+    // mostly closest-hit rays once a launch is small (profiles/r04_experiments.md).
+    constexpr bool STEAL = !COUNT && !HYB && MODE == kTraceAny;
+    const bool steal_on = STEAL && (refill_min & 0x8000u) != 0;
     const uint32_t n = n_first + n_b;
     bool is_any = MODE == kTraceAny;          // per lane in mixed mode
 #define CRAY_ANY_LANE (MODE == kTraceMixed ? is_any : (MODE == kTraceAny))
@@ -78,6 +102,13 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
     uint32_t sref[kStackDepth - kLdsStack];
     uint32_t skw0[kStackDepth - kLdsStack], skw1[kStackDepth - kLdsStack];
     const unsigned int tid = threadIdx.x;
+    // work sharing in the drain (STEAL): per ray that has been split — indexed by the thread that fetched it from the queue, its
+    // "owner" — the number of workers still walking and whether one of them found an occluder; `steal_pair` matches the k-th idle
+    // lane of a wave with its k-th donor.  All three are only ever touched by the lanes of ONE wave (its own 64 entries).
+    __shared__ uint32_t grp_cnt[STEAL ? kBlock : 1], grp_occ[STEAL ? kBlock : 1], steal_pair[STEAL ? kBlock : 1];
+    int sbase = 0;              // bottom of this lane's stack: entries [sbase, sp) are its own, [0, sbase) were given away
+    uint32_t owner = tid;       // thread whose grp_cnt / grp_occ entry this lane's ray uses
+    bool shared = false;        // this lane's ray has (had) other workers
     // (r_: reference, w0_ / w1_: the two payload words)
 #define CRAY_PUSH_W(r_, w0_, w1_)                                                          \
     do {                                                                                   \
@@ -124,275 +155,33 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
     float t_lo = 0.f, t_hi = 0.f;
     uint32_t res = 0;
     bool resolve = false;
+    bool have = false;   // HYB 2: the record of `cur` came with its parent's line and sits in c0..c3
+    // HYB 2: the second half of the pair line a lane fetched last (the companion child's record); kept across iterations
+    double2 c0 = make_double2(0.0, 0.0), c1 = c0, c2 = c0, c3 = c0;
 
-    for (;;) {
-        // ---- idle lanes fetch the next rays of the queue.  A wave reserves a chunk of consecutive queue
-        // positions with ONE atomic and hands them out over several refills, so that most refills do not
-        // start with a device-wide atomic round trip.
-        const unsigned long long idle = __ballot(!active);
-        // the shadow-ray part of a mixed launch has its own threshold (the high 16 bits of refill_min); since the round-3 compaction
-        // the best value is the path segments' (24-32 of 64 idle lanes, profiles/r03_refill_sweep_final.log), it used to be higher
-        const unsigned int refill_now = (MODE == kTraceMixed && res_base >= n_b) ? (refill_min >> 16) : (refill_min & 0xffffu);
-        const bool do_refill = (unsigned int)__popcll(idle) >= refill_now && !exhausted;
-        // Results of finished rays stay in registers until the wave refills (or drains): the stores then
-        // run once with many lanes instead of in almost every iteration with one or two.
-        if ((do_refill || idle == ~0ull) && pending) {
-            if (CRAY_ANY_LANE) {
-                const uint32_t l = ps.sp0[p];   // p is a shadow slot; L lives per original path
-                ps.lr[l] = ps.lr[l] + ps.cr[p];
-                ps.lg[l] = ps.lg[l] + ps.cg[p];
-                ps.lb[l] = ps.lb[l] + ps.cb[p];
-            } else {
-                ps.ht[p] = hit_t; ps.hu[p] = hit_u; ps.hv[p] = hit_v; ps.hprim[p] = hit_prim;
-            }
-            pending = false;
-        }
-        if (do_refill) {
-            if (res_left == 0) {
-                const unsigned int leader = __ffsll((long long)idle) - 1;
-                unsigned int base = 0;
-                if (lane == leader) base = atomicAdd(work_head, chunk);
-                base = __shfl(base, leader);
-                if (base >= n) { exhausted = true; }
-                else { res_base = base; res_left = n - base < chunk ? n - base : chunk; }
-            }
-            const unsigned int rank = (unsigned int)__popcll(idle & ((1ull << lane) - 1ull));
-            const bool take = !active && rank < res_left;
-            const unsigned int mine = res_base + rank;
-            const unsigned int taken = (unsigned int)__popcll(__ballot(take));
-#ifdef CRAY_TRACE_DIAG
-            dg[4] += 1; dg[5] += taken;
-#endif
-            res_base += taken; res_left -= taken;
-            if (take) {
-                if (MODE == kTraceMixed) {
-                    // virtual queue: the path segments (long jobs: ~56 nodes per ray) first, the shadow rays (~43) last, so that
-                    // the launch drains on short jobs
-                    is_any = mine >= n_b;
-                    if (is_any) p = queue[mine - n_b];
-                    else p = queue_b ? queue_b[mine] : mine;
-                } else {
-                    p = queue ? queue[mine] : mine;
-                }
-                if (CRAY_ANY_LANE) {
-                    ray.o = mk(ps.sox[p], ps.soy[p], ps.soz[p]);
-                    ray.d = mk(ps.sdx[p], ps.sdy[p], ps.sdz[p]);
-                    ray.tmax = ps.stmax[p];
-                } else {
-                    ray.o = mk(ps.ox[p], ps.oy[p], ps.oz[p]);
-                    ray.d = mk(ps.dx[p], ps.dy[p], ps.dz[p]);
-                    ray.tmax = closest_tmax ? closest_tmax[p] : inf64();  // path segments are Ray::new -> +inf
-                }
-                hit_t = 0.0; hit_u = 0.0; hit_v = 0.0; hit_prim = -1;
-                sp = 0;
-                rd = mk(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
-                dneg = (ray.d.x < 0.0 ? 1u : 0u) | (ray.d.y < 0.0 ? 2u : 0u) | (ray.d.z < 0.0 ? 4u : 0u);
-                fast_div = sc.bounds_in_div_range && div_fast_ok(ray.d.x) && div_fast_ok(ray.d.y) && div_fast_ok(ray.d.z) &&
-                           div_range_ok(ray.o.x) && div_range_ok(ray.o.y) && div_range_ok(ray.o.z);
-                if (HYB) {
-                    const HybRay hr_ = hyb_ray(ray.o, ray.d, rd, fast_div);
-                    h_ox = hr_.ox; h_oy = hr_.oy; h_oz = hr_.oz; h_rx = hr_.rx; h_ry = hr_.ry; h_rz = hr_.rz; h_a = hr_.a;
-                    hyb_tmax(ray.tmax, t_lo, t_hi);
-                    resolve = false;
-                }
-                if (COUNT) n_nodes += 1;
-                const double k_root = fast_div ? CRAY_CHILD_KEY(sc.root_lo, sc.root_hi, ray.o, ray.d, rd)
-                                               : child_key(sc.root_lo, sc.root_hi, ray.o, ray.d);
-                if (k_root < ray.tmax) {
-                    cur = sc.root_ref;
-                    active = true;
-                } else {
-                    pending = true;  // root rejected: miss / unoccluded
-                }
-            }
-        }
-        if (!__any(active)) {
-            if (exhausted) break;
-            continue;
-        }
-
-        bool need_pop = false, finished = false, occluded = false;
-#ifdef CRAY_TRACE_DIAG
-        {
-            const unsigned int na = (unsigned int)__popcll(__ballot(active));
-            const unsigned int nr = HYB ? (unsigned int)__popcll(__ballot(active && resolve)) : 0u;
-            const unsigned int nl = (unsigned int)__popcll(__ballot(active && !(HYB && resolve) && ref_is_leaf(cur)));
-            dg[0] += 1; dg[1] += na; dg[6] += na - nl - nr; dg[7] += nl; dg[8] += nr; dg[9] += nr ? 1 : 0;
-            dg[10] += nl ? 1 : 0;
-            {
-                // leaves whose FIRST slot is not a triangle, leaves with more than one slot (diagnostics read the slot kind themselves)
-                bool other = false, multi = false;
-                if (active && !(HYB && resolve) && ref_is_leaf(cur)) {
-                    other = sc.slots[ref_leaf_first(cur)].kind != CRAY_SHAPE_TRIANGLE;
-                    multi = ref_leaf_count(cur) > 1;
-                }
-                dg[11] += __any(other) ? 1 : 0; dg[12] += __any(multi) ? 1 : 0;
-                dg[13] += (unsigned int)__popcll(__ballot(other));
-            }
-            if (exhausted) { dg[2] += 1; dg[3] += na; }
-        }
-#endif
-        // ---- one record fetch per iteration: the interior node `cur` (7 x 16 B) or the first slot of
-        // the leaf `cur` (5 x 16 B) through the SAME seven load instructions, hence one memory wait per
-        // iteration for the whole wave instead of one for the node and a dependent one for the leaf.
-        // HYB: the interior node is 4 x 16 B of f32, a RESOLVE step reads the 3 x 16 B of one child's f64 bounds: five loads.
-        const bool at_leaf = !(HYB && resolve) && ref_is_leaf(cur);
-        // (the record registers of an idle lane stay undefined: nothing below reads them, and zeroing 14 registers per iteration
-        // is 5 % of the loop's VALU instructions.  Loading in idle lanes as well instead was measured: +8 %, the texture
-        // addresser is nearly as busy as the VALU.)
-        double2 r0, r1, r2, r3, r4, r5, r6;
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Wsometimes-uninitialized"
-#pragma clang diagnostic ignored "-Wconditional-uninitialized"
-        if (HYB) {
-            if (active) {
-                const double2* rec = resolve ? reinterpret_cast<const double2*>(reinterpret_cast<const char*>(sc.inner + (res & 0x7fffffffu)) + (res >> 31) * 48u)
-                                   : at_leaf ? reinterpret_cast<const double2*>(sc.slots + ref_leaf_first(cur))
-                                             : reinterpret_cast<const double2*>(sc.innerh + cur);
-                r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
-                if (!resolve) r3 = rec[3];
-                if (at_leaf) r4 = rec[4];
-            }
-        } else {
-            // the wave that is about to request its records goes first: its loads are what everything after waits for
-            // (s_setprio: -0.4 % on configs[2] and [3], consistently)
-            __builtin_amdgcn_s_setprio(3);
-            if (active) {
-                const double2* rec = at_leaf ? reinterpret_cast<const double2*>(sc.slots + ref_leaf_first(cur))
-                                             : reinterpret_cast<const double2*>(sc.inner + cur);
-                r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3]; r4 = rec[4]; r5 = rec[5]; r6 = rec[6];
-            }
-            __builtin_amdgcn_s_setprio(0);
-        }
-        if (HYB && active && resolve) {
-            // the decision that brought the lane to `cur`, retaken exactly (bounds.rs:46-88 in f64)
-            const double lo[3] = {r0.x, r0.y, r1.x}, hi[3] = {r1.y, r2.x, r2.y};
-            const double key = fast_div ? child_key_fast(lo, hi, ray.o, ray.d, rd) : child_key(lo, hi, ray.o, ray.d);
-            resolve = false;
-            if (!(key < ray.tmax)) need_pop = true;   // otherwise the lane is at `cur` for good: its record is fetched next iteration
-        } else if (HYB && active && !at_leaf) {
-            // a double of the record = one coordinate of both children (InnerNodeH)
-#define CRAY_F2(d_) __builtin_bit_cast(hyb_f2, d_)
-            const HybNode hn = hyb_node(CRAY_F2(r0.x), CRAY_F2(r0.y), CRAY_F2(r1.x), CRAY_F2(r1.y), CRAY_F2(r2.x), CRAY_F2(r2.y), h_ox, h_oy, h_oz, h_rx, h_ry, h_rz, h_a, t_lo, t_hi);
-#undef CRAY_F2
-            const uint32_t ref0 = (uint32_t)__double2loint(r3.x), ref1 = (uint32_t)__double2hiint(r3.x);
-            const uint32_t axis = (uint32_t)__double2loint(r3.y);
-            const bool right_first = ((dneg >> axis) & 1u) != 0;   // bvh.rs:92-98: dir[axis] < 0
-            const uint32_t near = right_first ? ref1 : ref0, far = right_first ? ref0 : ref1;
-            const float kcf = right_first ? hn.kc[0] : hn.kc[1];
-            const uint32_t par_n = cur | (right_first ? 0x80000000u : 0u), par_f = cur | (right_first ? 0u : 0x80000000u);
-            const int sn = right_first ? hn.s[1] : hn.s[0], sf = right_first ? hn.s[0] : hn.s[1];
-            if (COUNT && !ANY) n_nodes += 2;  // both children are popped and tested by the reference
-            if (COUNT && ANY) {
-                // count pops in the reference's order: near now, far when (if) it is popped
-                n_nodes += 1;
-                CRAY_PUSH_H(far, kcf, par_f);
-                if (sn != kHybCull) { cur = near; res = par_n; resolve = sn == kHybResolve; } else need_pop = true;
-            } else if (sn != kHybCull) {
-                // an uncertified far child is deferred like a certified one: its key does not depend on ray.tmax, the test
-                // at its pop (certified then, or exact) is the reference's test of that pop
-                if (sf != kHybCull) CRAY_PUSH_H(far, kcf, par_f);
-                cur = near; res = par_n; resolve = sn == kHybResolve;
-            } else if (sf != kHybCull) {
-                cur = far; res = par_f; resolve = sf == kHybResolve;
-            } else {
-                need_pop = true;
-            }
-        } else if (!HYB && active && !at_leaf) {
-            const double lo0[3] = {r0.x, r0.y, r1.x}, hi0[3] = {r1.y, r2.x, r2.y};
-            const double lo1[3] = {r3.x, r3.y, r4.x}, hi1[3] = {r4.y, r5.x, r5.y};
-            const unsigned long long refs = (unsigned long long)__double_as_longlong(r6.x);
-            const uint32_t ref0 = (uint32_t)refs, ref1 = (uint32_t)(refs >> 32);
-            const uint32_t axis = (uint32_t)(unsigned long long)__double_as_longlong(r6.y);
-            double k0, k1;
-            if (fast_div) { k0 = CRAY_CHILD_KEY(lo0, hi0, ray.o, ray.d, rd); k1 = CRAY_CHILD_KEY(lo1, hi1, ray.o, ray.d, rd); }
-            else { k0 = child_key(lo0, hi0, ray.o, ray.d); k1 = child_key(lo1, hi1, ray.o, ray.d); }
-            // bvh.rs:92-98: dir[axis] < 0 -> push left, push right => right is visited first
-            const bool right_first = ((dneg >> axis) & 1u) != 0;
-            const uint32_t near = right_first ? ref1 : ref0, far = right_first ? ref0 : ref1;
-            const double kn = right_first ? k1 : k0, kf = right_first ? k0 : k1;
-            const bool an = kn < ray.tmax, af = kf < ray.tmax;
-            if (COUNT && !ANY) n_nodes += 2;  // both children are popped and tested by the reference
-            if (COUNT && ANY) {
-                // count pops in the reference's order: near now, far when (if) it is popped
-                n_nodes += 1;
-                CRAY_PUSH(far, kf);
-                if (an) cur = near; else need_pop = true;
-            } else if (an) {
-                if (af) CRAY_PUSH(far, kf);
-                cur = near;
-            } else if (af) {
-                cur = far;
-            } else {
-                need_pop = true;
-            }
-        } else if (active) {
-            // ONE slot per iteration: a leaf of several primitives (13 % of the dragon's hold 2, none more than 4) keeps its lane
-            // for as many iterations — `cur` steps to the leaf's remaining slots — so that no iteration waits for a second,
-            // dependent record fetch (a quarter to a half of all iterations did) and the later slots of one lane are tested
-            // together with the first slots of others.
-            const unsigned long long tag = (unsigned long long)__double_as_longlong(r4.y);
-            const uint32_t s_prim = (uint32_t)tag, s_kind = (uint32_t)(tag >> 32);
-            if (COUNT) n_prims += 1;
-            if (s_kind == CRAY_SHAPE_TRIANGLE) {
-                if (COUNT) n_tri += 1;
-                double t, u, v;
-                if (tri_test(mk(r0.x, r0.y, r1.x), mk(r1.y, r2.x, r2.y), mk(r3.x, r3.y, r4.x), ray, t, u, v)) {
-                    if (CRAY_ANY_LANE) occluded = true;
-                    else {
-                        ray.tmax = t;  // Ray::update_max_distance
-                        if (HYB) hyb_tmax(t, t_lo, t_hi);
-                        hit_t = t; hit_u = u; hit_v = v; hit_prim = (int32_t)s_prim;
-                    }
-                }
-            } else {
-                const uint32_t shp = (uint32_t)__double2loint(r0.x);   // the slot of a sphere / disk carries its index (no prims[] hop)
-                const bool hit = s_kind == CRAY_SHAPE_SPHERE ? sphere_hit(sc.spheres[shp], ray, CRAY_ANY_LANE, nullptr)
-                                                             : disk_hit(sc.disks[shp], ray, CRAY_ANY_LANE, nullptr);
-                if (hit) {
-                    if (CRAY_ANY_LANE) occluded = true;
-                    else {
-                        hit_t = ray.tmax; hit_prim = (int32_t)s_prim;  // distance: ray.max_distance (primitive.rs:66)
-                        if (HYB) hyb_tmax(ray.tmax, t_lo, t_hi);
-                    }
-                }
-            }
-            if (CRAY_ANY_LANE && occluded) finished = true;
-            else if (ref_leaf_count(cur) > 1) cur += 7u;   // first slot + 1 (<< 3), count - 1
-            else need_pop = true;
-        }
-#pragma clang diagnostic pop
-        // ---- pop: a deferred child is re-tested against the current (shrunken) ray.tmax
-#ifdef CRAY_TRACE_DIAG
-        dg[15] += __any(active && need_pop) ? 1 : 0;
-        unsigned int trips = 0;
-#endif
-        if (active && need_pop) {
-            for (;;) {
-#ifdef CRAY_TRACE_DIAG
-                trips++;
-#endif
-                if (sp == 0) { finished = true; break; }
-                --sp;
-                if (COUNT && ANY) n_nodes += 1;
-                uint32_t ref, w0, w1;
-                CRAY_POP_W(ref, w0, w1);
-                if (HYB) {
-                    const int st = hyb_status(__uint_as_float(w0), h_a, t_lo, t_hi);
-                    if (st != kHybCull) { cur = ref; res = w1; resolve = st == kHybResolve; break; }
-                } else {
-                    const double key = __hiloint2double((int)w1, (int)w0);
-                    if (key < ray.tmax) { cur = ref; break; }
-                }
-            }
-        }
-#ifdef CRAY_TRACE_DIAG
-        for (int o_ = 32; o_; o_ >>= 1) { const unsigned int t_ = (unsigned int)__shfl_xor((int)trips, o_); trips = t_ > trips ? t_ : trips; }
-        dg[14] += trips;   // trips of the pop loop as the wave runs it: the maximum over its lanes
-#endif
-        if (active && finished) {
-            pending = CRAY_ANY_LANE ? !occluded : true;
-            active = false;
+    if constexpr (HYB != 0) {
+        // (how the loop is spelled: see the head of cray_trace_step.inc)
+        auto step = [&]() __attribute__((always_inline)) -> bool {
+#define CRAY_STEP_DRAIN false
+#define CRAY_STEP_BREAK return true
+#define CRAY_STEP_CONTINUE return false
+#include "cray_trace_step.inc"
+#undef CRAY_STEP_DRAIN
+#undef CRAY_STEP_BREAK
+#undef CRAY_STEP_CONTINUE
+            return false;
+        };
+        for (;;)
+            if (step()) break;
+    } else {
+        for (;;) {
+#define CRAY_STEP_DRAIN (STEAL && steal_on && exhausted)
+#define CRAY_STEP_BREAK break
+#define CRAY_STEP_CONTINUE continue
+#include "cray_trace_step.inc"
+#undef CRAY_STEP_DRAIN
+#undef CRAY_STEP_BREAK
+#undef CRAY_STEP_CONTINUE
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -420,16 +209,16 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
 #undef CRAY_ANY_LANE
 }
 
-template <bool ANY, bool COUNT, bool HYB>
-__global__ void __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace(DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
+template <bool ANY, bool COUNT, int HYB>
+__global__ void CRAY_TRACE_EU __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace(DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
                                                   const unsigned int* __restrict__ n_ptr, uint32_t n_fixed,
                                                   const double* __restrict__ closest_tmax, Counters* ctr, unsigned int* work_head, unsigned int refill_min) {
     trace_body<ANY ? kTraceAny : kTraceClosest, COUNT, HYB>(sc, ps, queue, n_ptr ? *n_ptr : n_fixed, nullptr, 0u, closest_tmax, ctr, work_head, refill_min);
 }
 
 // shadow rays of one bounce (any_queue) + path segments of the next (closest_queue) in one persistent launch
-template <bool HYB>
-__global__ void __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace_mixed(DevScene sc, PathState ps, const uint32_t* __restrict__ any_queue,
+template <int HYB>
+__global__ void CRAY_TRACE_EU __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace_mixed(DevScene sc, PathState ps, const uint32_t* __restrict__ any_queue,
                                                   const unsigned int* __restrict__ n_any_ptr, const uint32_t* __restrict__ closest_queue,
                                                   const unsigned int* __restrict__ n_closest_ptr, Counters* ctr, unsigned int* work_head,
                                                   unsigned int refill_min) {
@@ -678,6 +467,35 @@ __global__ void __launch_bounds__(kBlock) k_make_innerh(const InnerNode* __restr
         o.lo[k][1] = f32_down(a.lo1[k]); o.hi[k][1] = f32_up(a.hi1[k]);
     }
     o.ref0 = a.ref0; o.ref1 = a.ref1; o.axis = a.axis; o.pad_ = 0;
+    out[i] = o;
+}
+// pair lines: a node's certified-f32 record followed by the record of one interior child.  pick 0: the left child when it is
+// interior, else the right one; pick 1: the interior child with the larger surface area (the more likely descent).
+__device__ __forceinline__ InnerNodeH make_h(const InnerNode& a) {
+    InnerNodeH o;
+    for (int k = 0; k < 3; k++) {
+        o.lo[k][0] = f32_down(a.lo0[k]); o.hi[k][0] = f32_up(a.hi0[k]);
+        o.lo[k][1] = f32_down(a.lo1[k]); o.hi[k][1] = f32_up(a.hi1[k]);
+    }
+    o.ref0 = a.ref0; o.ref1 = a.ref1; o.axis = a.axis; o.pad_ = 0;
+    return o;
+}
+__global__ void __launch_bounds__(kBlock) k_make_innerp(const InnerNode* __restrict__ in, uint32_t n, InnerNodeP* __restrict__ out, uint32_t pick) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const InnerNode a = in[i];
+    InnerNodeP o;
+    o.self = make_h(a);
+    const bool in0 = !ref_is_leaf(a.ref0), in1 = !ref_is_leaf(a.ref1);
+    uint32_t code = in0 ? 1u : (in1 ? 2u : 0u);
+    if (pick == 1u && in0 && in1) {
+        const double x0 = a.hi0[0] - a.lo0[0], y0 = a.hi0[1] - a.lo0[1], z0 = a.hi0[2] - a.lo0[2];
+        const double x1 = a.hi1[0] - a.lo1[0], y1 = a.hi1[1] - a.lo1[1], z1 = a.hi1[2] - a.lo1[2];
+        code = (x1 * y1 + y1 * z1 + z1 * x1) > (x0 * y0 + y0 * z0 + z0 * x0) ? 2u : 1u;
+    }
+    o.self.pad_ = code;
+    if (code) o.comp = make_h(in[code == 1u ? a.ref0 : a.ref1]);
+    else { InnerNodeH z; __builtin_memset(&z, 0, sizeof(z)); o.comp = z; }
     out[i] = o;
 }
 __global__ void __launch_bounds__(kBlock) k_make_slots32(const LeafSlot* __restrict__ in, uint32_t n, LeafSlot32* __restrict__ out) {

@@ -146,7 +146,11 @@ typedef struct {
                                                ray the call fails with CRAY_ERR_UNSUPPORTED) */
     double seconds;                         /* first launch -> film complete, host clock around a device sync */
     double trace_closest_ms, trace_any_ms, shade_ms, other_ms; /* HIP-event time per kernel family */
-    uint32_t trace_closest_launches, trace_any_launches, shade_launches, pad_;
+    uint32_t trace_closest_launches, trace_any_launches, shade_launches;
+    uint32_t trace_records;                 /* which records the traversal launches of this call read: low nibble the bounce-0
+                                               launch, next nibble the others; 0 f64, 1 certified f32 culling, 2 pair lines.  The
+                                               hits are the reference's either way; by default the library picks per
+                                               scene whichever its first two frames show to be faster */
     double trace_mixed_ms;                  /* launches that trace the shadow rays of bounce b together with the
                                                path segments of bounce b+1 (not used with count_traversal) */
     uint32_t trace_mixed_launches, pad2_;

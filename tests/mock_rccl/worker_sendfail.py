@@ -60,7 +60,9 @@ elif rank == 0:
 else:
     assert rc == 0, (rc, msg)                             # a rank whose own send went through has nothing to report
 
-# frame 3: the same communicator, the same buffers
+# frame 3: the same communicator, the same buffers.  (Rank 0 sat in its receive for MOCK_RCCL_STUCK_MS = 3 s; the stand-in applies
+# that patience to every wait, so the ranks that came back at once wait here rather than inside the barrier.)
+time.sleep(max(0.0, t0 + 5.0 - time.time()))
 ctx.barrier()
 got, _ = scene.render_gather(seed=3)
 if rank == 0:

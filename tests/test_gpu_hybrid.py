@@ -1,6 +1,9 @@
 """The opt-in certified f32 culling of the exact traversal (CRAY_HYBRID=1): 64-B f32 node records decide what
 they can certify, everything else is retaken from the f64 record.  It must change nothing: hits, distances and the node /
-primitive counters against the oracle, films bit for bit against the default (f64 records) context."""
+primitive counters against the oracle, films bit for bit against the default (f64 records) context.
+CRAY_HYBRID=2 (round 4) is the same with pair lines — a node's record and the record of one interior child in one 128-B line,
+the child's record carried in registers when the lane descends into it: timed kernels only (the counting launches of such a
+context run the plain f64 kernels), so its any-hit answers, hit records and films are what is checked here."""
 import numpy as np
 import pytest
 
@@ -11,11 +14,11 @@ from tests.parity_util import small_scenes, random_rays
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope='module')
-def ctxs():
+@pytest.fixture(scope='module', params=['1', '2'])
+def ctxs(request):
     import os
     old = os.environ.get('CRAY_HYBRID')
-    os.environ['CRAY_HYBRID'] = '1'          # read when the context is created
+    os.environ['CRAY_HYBRID'] = request.param          # read when the context is created
     hyb = backend.Context(0)
     os.environ['CRAY_HYBRID'] = '0'
     ref = backend.Context(0)
@@ -62,6 +65,8 @@ def test_hybrid_traversal_is_the_reference_traversal(ctxs, name):
     # the timed kernels (no counting) find the same hits
     gt, _ = dev.trace(rays, timed=True)
     assert np.array_equal(gt['prim'], g['prim']) and np.array_equal(gt['t'], g['t'])
+    gat, _ = dev.trace(rays, any_hit=True, timed=True)
+    assert np.array_equal(gat['hit'], oa['hit'])
     dev.close()
 
 
@@ -81,6 +86,38 @@ def test_hybrid_film_is_the_default_film(ctxs, name):
     for k in ('closest_nodes', 'closest_prims', 'shadow_nodes', 'shadow_prims'):
         assert sh2[k] == sr2[k], k
     dh.close(); dr.close()
+
+
+def test_a_context_that_chooses_its_records_per_scene_renders_the_same_film():
+    """Default contexts (CRAY_HYBRID unset) time a scene's first frame on f64 records and its second on certified f32 culling and
+    keep, per launch kind, whichever was faster (cray_stats.trace_records says which records a call read).  The choice must never
+    show in the film: all three frames equal the oracle's, bit for bit.  Frames too small to time stay on f64 records."""
+    import os
+    old = os.environ.pop('CRAY_HYBRID', None)
+    try:
+        ctx = backend.Context(0)
+    finally:
+        if old is not None:
+            os.environ['CRAY_HYBRID'] = old
+    from craytracer_amd import scenes
+    sc = scenes.dragon(512, 288, 16, 6, nu=200, nv=500)          # 2.36 M paths: big enough to be timed
+    dev = ctx.upload(backend.HostScene(sc, resident=True))
+    ref, _ = ol.OracleScene(sc).render(seed=2)
+    seen = []
+    for _ in range(4):
+        f, st = dev.render(seed=2)
+        assert np.array_equal(f, ref)
+        seen.append(st['trace_records'])
+    assert seen[0] == 0x00 and seen[1] == 0x11, seen                       # the two timed frames
+    assert seen[2] == seen[3] and (seen[2] & 15) in (0, 1) and (seen[2] >> 4) in (0, 1), seen   # the choice, kept
+    fc, stc = dev.render(seed=2, count_traversal=True)                       # counting frames always read f64 records
+    assert stc['trace_records'] == 0 and np.array_equal(fc, ref)
+    dev.close()
+    small = ctx.upload(backend.HostScene(dict(small_scenes())['cornell']))
+    for _ in range(3):
+        assert small.render(seed=1)[1]['trace_records'] == 0
+    small.close()
+    ctx.close()
 
 
 @pytest.mark.parametrize('name', ['test', 'staircase', 'dragon'])
