@@ -55,6 +55,9 @@ WORKLOADS = {
 }
 
 
+RECORD_NAMES = ['f64', 'certified f32 culling', 'pair lines'] + ['?'] * 13
+
+
 def make_scene(scenes, name):
     wl = dict(WORKLOADS[name])
     factory = getattr(scenes, wl.pop('scene'))
@@ -467,8 +470,8 @@ def main():
                                    # which records the traversal launches of the timed frames read (cray_stats.trace_records): both give
                                    # the reference's hits bit for bit; the library keeps per scene and launch kind whichever its first
                                    # two frames showed to be faster
-                                   'trace_records': {'bounce0': ['f64', 'certified f32 culling', 'pair lines'][stats[-1]['trace_records'] & 15],
-                                                     'other_launches': ['f64', 'certified f32 culling', 'pair lines'][(stats[-1]['trace_records'] >> 4) & 15]}},
+                                   'trace_records': {'bounce0': RECORD_NAMES[stats[-1]['trace_records'] & 15],
+                                                     'other_launches': RECORD_NAMES[(stats[-1]['trace_records'] >> 4) & 15]}},
         }
         if args.precision != 'f64' and world == 1:
             # how far the fast film is from the exact one: both rendered here, RMSE over RGB (north star: < 1e-4 for the exact path)

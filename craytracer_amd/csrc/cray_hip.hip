@@ -58,6 +58,7 @@ struct cray_ctx {
     // idle lanes a wave waits for before it fetches new rays: the coherent camera rays of bounce 0 finish together (late refills
     // cost little and keep neighbouring pixels in one wave), the incoherent later bounces refill earlier (profiles/r02_experiments.md)
     unsigned int refill_min = 28, refill_min_b0 = 64, refill_min_any = 28;
+    unsigned int lds_shapes = 1;   // the few sphere / disk records of a scene staged in LDS by the traversal launches (CRAY_LDS_SHAPES=0: read global memory)
     unsigned int steal = 1;   // work sharing among the lanes of a wave in the drain of the shadow-ray launches (trace_body, STEAL); CRAY_STEAL=0 turns it off
     int trace_blocks_per_cu = 4;
     int trace32_blocks_per_cu = 4;
@@ -77,6 +78,7 @@ struct cray_ctx {
     int hybrid = -1;    // records the exact traversal reads: 0 f64, 1 certified f32 culling (same results), 2 the same with
                         // pair lines; -1 (default) = per scene and per launch kind, whichever of 0 / 1 the first two frames show to be
                         // faster (render_local).  CRAY_HYBRID=0/1/2 pins it.
+    int records_b0 = -1, records_rest = -1;   // CRAY_RECORDS_B0 / CRAY_RECORDS_REST (0 / 1): pin the records per launch kind instead of timing
     int pair_pick = 0;  // pair lines: which interior child shares its parent's line (0 left first, 1 larger surface area)
     int mix_trace = 1;  // shadow rays of bounce b and segments of bounce b+1 in one launch (CRAY_MIX_TRACE=0 disables)
     int log_queues = 0; // CRAY_LOG_QUEUES=1 (diagnostics): after every bounce, sync and print the queue lengths to stderr
@@ -340,11 +342,14 @@ extern "C" int cray_ctx_create(int device_id, void* stream, cray_ctx** out) {
     c->mix_trace = env_int("CRAY_MIX_TRACE", 0, 1, c->mix_trace);
     c->hybrid = env_int("CRAY_HYBRID", -1, 2, c->hybrid);
     c->pair_pick = env_int("CRAY_PAIR_PICK", 0, 1, c->pair_pick);
+    c->records_b0 = env_int("CRAY_RECORDS_B0", -1, 1, c->records_b0);
+    c->records_rest = env_int("CRAY_RECORDS_REST", -1, 1, c->records_rest);
     c->log_queues = env_int("CRAY_LOG_QUEUES", 0, 1, 0);
     c->refill_min = (unsigned int)env_int("CRAY_REFILL_MIN", 1, 64, (int)c->refill_min);
     c->refill_min_b0 = (unsigned int)env_int("CRAY_REFILL_MIN_B0", 1, 64, (int)c->refill_min_b0);
     c->refill_min_any = (unsigned int)env_int("CRAY_REFILL_MIN_ANY", 1, 64, (int)c->refill_min_any);
     c->steal = (unsigned int)env_int("CRAY_STEAL", 0, 1, (int)c->steal);
+    c->lds_shapes = (unsigned int)env_int("CRAY_LDS_SHAPES", 0, 1, (int)c->lds_shapes);
     c->trace_blocks_per_cu = env_int("CRAY_TRACE_BLOCKS_PER_CU", 1, 16, c->trace_blocks_per_cu);
     c->shade_blocks_per_cu = env_int("CRAY_SHADE_BLOCKS_PER_CU", 0, 64, c->shade_blocks_per_cu);
     c->trace32_blocks_per_cu = env_int("CRAY_TRACE32_BLOCKS_PER_CU", 1, 16, c->trace32_blocks_per_cu);
@@ -1026,6 +1031,8 @@ int choose_trace_records(cray_ctx* c, cray_scene* s, bool counting, size_t n_pat
     if (c->hybrid >= 0) {
         // the counting launches of a pair-line context run the plain f64 kernels (equal counters by construction)
         s->use_b0 = s->use_rest = (c->hybrid == 2 && counting) ? 0 : c->hybrid;
+    } else if (c->records_b0 >= 0 && c->records_rest >= 0 && !counting) {
+        s->use_b0 = c->records_b0; s->use_rest = c->records_rest;   // pinned per launch kind (profiling passes: tools/profile_round.sh)
     } else if (counting) {
         s->use_b0 = s->use_rest = 0;
     } else if (s->tune_stage >= 2) {
@@ -1091,6 +1098,36 @@ struct ShadeLaunch<kNumShadeVariants> {
     static void go(int, int, bool, const cray_ctx*, size_t, hipStream_t, A...) {}
 };
 
+// The traversal launches: which records they read (v: 0 f64, 1 certified f32 culling, 2 pair lines) and whether the scene's few
+// sphere / disk records are staged in LDS (shp: those instantiations get bit 14 of refill_min) pick the instantiation.
+// Counting launches exist for v 0 and 1 only; the f64 any-hit launch keeps its LDS for the work sharing.
+template <bool ANY, bool COUNT, class... A>
+void launch_trace(int v, bool shp, int grid, hipStream_t st, A... a) {
+    const dim3 g(grid), b(kBlock);
+    if constexpr (COUNT) {
+        if (v == 1) hipLaunchKernelGGL((k_trace<ANY, true, 1>), g, b, 0, st, a...);
+        else hipLaunchKernelGGL((k_trace<ANY, true, 0>), g, b, 0, st, a...);
+    } else {
+        if (v == 2) hipLaunchKernelGGL((k_trace<ANY, false, 2>), g, b, 0, st, a...);
+        else if (v == 1 && shp) hipLaunchKernelGGL((k_trace<ANY, false, 1, true>), g, b, 0, st, a...);
+        else if (v == 1) hipLaunchKernelGGL((k_trace<ANY, false, 1>), g, b, 0, st, a...);
+        else if (shp && !ANY) hipLaunchKernelGGL((k_trace<false, false, 0, true>), g, b, 0, st, a...);
+        else hipLaunchKernelGGL((k_trace<ANY, false, 0>), g, b, 0, st, a...);
+    }
+}
+template <class... A>
+void launch_mixed(int v, bool shp, int grid, hipStream_t st, A... a) {
+    const dim3 g(grid), b(kBlock);
+    if (v == 2) hipLaunchKernelGGL(k_trace_mixed<2>, g, b, 0, st, a...);
+    else if (v == 1 && shp) hipLaunchKernelGGL((k_trace_mixed<1, true>), g, b, 0, st, a...);
+    else if (v == 1) hipLaunchKernelGGL(k_trace_mixed<1>, g, b, 0, st, a...);
+    else if (shp) hipLaunchKernelGGL((k_trace_mixed<0, true>), g, b, 0, st, a...);
+    else hipLaunchKernelGGL(k_trace_mixed<0>, g, b, 0, st, a...);
+}
+bool shapes_fit_lds(const cray_ctx* c, const DevScene& d) {
+    return c->lds_shapes && d.n_spheres + d.n_disks > 0 && d.n_spheres + d.n_disks <= kTraceLdsShapes;
+}
+
 int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const PassPlan& pp, EventTimer* tm) {
     const DevScene& d = s->dev;
     const uint32_t spp_pass = pp.s_hi - pp.s_lo;
@@ -1112,14 +1149,8 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
     // kind keeps its own launch so that the counters stay per kind.
     const bool mixed = !count && c->mix_trace;
     const bool fast = prm.precision == CRAY_PRECISION_F32_TRAVERSAL;   // check_render_args refuses it together with counting
-    // which records the launches read (cray_scene::use_b0 / use_rest): 0 f64, 1 certified f32 culling (cray_math.h hyb_key),
-    // 2 the same with pair lines (timed launches only).  Same results whichever.
-#define CRAY_LAUNCH_TRACE(V_, ANY_, COUNT_, ...)                                                                               \
-    do {                                                                                                                        \
-        if ((V_) == 2 && !COUNT_) hipLaunchKernelGGL((k_trace<ANY_, false, 2>), dim3(g_trace), dim3(kBlock), 0, st, __VA_ARGS__); \
-        else if ((V_) == 1) hipLaunchKernelGGL((k_trace<ANY_, COUNT_, 1>), dim3(g_trace), dim3(kBlock), 0, st, __VA_ARGS__);      \
-        else hipLaunchKernelGGL((k_trace<ANY_, COUNT_, 0>), dim3(g_trace), dim3(kBlock), 0, st, __VA_ARGS__);                     \
-    } while (0)
+    const bool shp = shapes_fit_lds(c, d);
+    const unsigned int shp_bit = shp ? 0x4000u : 0u;
     const unsigned int trace_all = prm.count_traversal == 1 ? 1u : 0u;  // 2 = count, but keep skipping zero-term shadow rays
     for (uint32_t b = 0; b < d.max_depth; b++) {
         // live state of bounce b sits in view b & 1 (k_raygen wrote view 0), k_shade moves the survivors to the other one
@@ -1137,9 +1168,9 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
             HIP_TRY(hipMemsetAsync(&ctr->trace_head, 0, sizeof(unsigned int), st));
             if (tm) { int e = tm->begin(FAM_CLOSEST); if (e) return e; }
             const int v_closest = b == 0 ? s->use_b0 : s->use_rest;
-            if (count) CRAY_LAUNCH_TRACE(v_closest, false, true, d, ps_b, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
+            if (count) launch_trace<false, true>(v_closest, shp, g_trace, st, d, ps_b, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
             else if (fast) hipLaunchKernelGGL((k_trace32<kTraceClosest>), dim3(g_trace32), dim3(kBlock), 0, st, d, ps_b, q, nq, n_paths, (const uint32_t*)nullptr, (const unsigned int*)nullptr, ctr, &ctr->trace_head, b == 0 ? c->refill_min_b0 : c->refill_min, b == 0 ? 1u : 0u);
-            else CRAY_LAUNCH_TRACE(v_closest, false, false, d, ps_b, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, b == 0 ? c->refill_min_b0 : c->refill_min);
+            else launch_trace<false, false>(v_closest, shp, g_trace, st, d, ps_b, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, (b == 0 ? c->refill_min_b0 : c->refill_min) | shp_bit);
             if (tm) { int e = tm->end(); if (e) return e; }
         }
 
@@ -1156,19 +1187,17 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
             if (tm) { int e = tm->begin(FAM_MIXED); if (e) return e; }
             if (fast) hipLaunchKernelGGL((k_trace32<kTraceMixed>), dim3(g_trace32), dim3(kBlock), 0, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, 0u,
                                          (const uint32_t*)q_next, (const unsigned int*)n_next, ctr, &ctr->trace_head, c->refill_min, 0u);
-            else if (s->use_rest == 2) hipLaunchKernelGGL(k_trace_mixed<2>, dim3(g_trace), dim3(kBlock), 0, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow,
-                               (const uint32_t*)q_next, (const unsigned int*)n_next, ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16) | (c->steal ? 0x8000u : 0u));
-            else if (s->use_rest == 1) hipLaunchKernelGGL(k_trace_mixed<1>, dim3(g_trace), dim3(kBlock), 0, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow,
-                               (const uint32_t*)q_next, (const unsigned int*)n_next, ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16) | (c->steal ? 0x8000u : 0u));
-            else hipLaunchKernelGGL(k_trace_mixed<0>, dim3(g_trace), dim3(kBlock), 0, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow,
-                               (const uint32_t*)q_next, (const unsigned int*)n_next, ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16) | (c->steal ? 0x8000u : 0u));
+            else launch_mixed(s->use_rest, shp, g_trace, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, (const uint32_t*)q_next,
+                              (const unsigned int*)n_next, ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16) | (c->steal ? 0x8000u : 0u) | shp_bit);
             if (tm) { int e = tm->end(); if (e) return e; }
         } else {
             if (tm) { int e = tm->begin(FAM_ANY); if (e) return e; }
-            if (count) CRAY_LAUNCH_TRACE(s->use_rest, true, true, d, ps_n, c->shadow_queue, &ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
+            if (count) launch_trace<true, true>(s->use_rest, shp, g_trace, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
             else if (fast) hipLaunchKernelGGL((k_trace32<kTraceAny>), dim3(g_trace32), dim3(kBlock), 0, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, 0u,
                                               (const uint32_t*)nullptr, (const unsigned int*)nullptr, ctr, &ctr->trace_head, c->refill_min, 0u);
-            else CRAY_LAUNCH_TRACE(s->use_rest, true, false, d, ps_n, c->shadow_queue, &ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min_any | (c->steal ? 0x8000u : 0u));
+            // (the any-hit launch of the last bounce is all drain: the f64 instantiation, which shares work between lanes, beats
+            // the f32 culling there — 0.22 against 0.47 ms at an eighth of configs[2])
+            else launch_trace<true, false>((s->use_rest == 1 && c->steal) ? 0 : s->use_rest, shp, g_trace, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min_any | (c->steal ? 0x8000u : 0u) | shp_bit);
             if (tm) { int e = tm->end(); if (e) return e; }
         }
         if (c->log_queues) {   // diagnostics only: a host round trip per bounce
@@ -1194,7 +1223,6 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
                            prm.sample_batch, c->film, ctr);
     }
     if (tm) { int e = tm->end(); if (e) return e; }
-#undef CRAY_LAUNCH_TRACE
     HIP_TRY(hipGetLastError());
     return CRAY_OK;
 }
@@ -1207,7 +1235,7 @@ int check_render_args(cray_ctx* c, cray_scene* s, const cray_render_params* p) {
         return CRAY_ERR_INVALID;
     }
     if (p->precision > CRAY_PRECISION_F32_TRAVERSAL) { set_last_error("cray_render: unknown precision"); return CRAY_ERR_INVALID; }
-    if (p->precision == CRAY_PRECISION_F32_TRAVERSAL && p->count_traversal) {
+    if (p->precision != CRAY_PRECISION_F64 && p->count_traversal) {
         set_last_error("cray_render: the traversal counters are defined by the reference's f64 traversal; not available in the f32 fast mode");
         return CRAY_ERR_INVALID;
     }
@@ -1304,6 +1332,7 @@ int render_local(cray_ctx* c, cray_scene* s, const cray_render_params* prm, cray
     int measuring = -1;   // >= 0: this frame's traversal times decide which records the scene's later frames read
     if ((e = choose_trace_records(c, s, prm->count_traversal != 0 || prm->precision != CRAY_PRECISION_F64,
                                   n_pix_rank * (size_t)(s_end > s_begin ? s_end - s_begin : 0), &measuring))) return e;
+    const uint32_t used_records = (uint32_t)(s->use_b0 | (s->use_rest << 4));   // what THIS call's launches read (cray_stats.trace_records)
     const size_t film_floats = (size_t)W * H * 3;
     if ((e = ensure_buffer(&c->film, &c->film_floats, film_floats))) return e;
     // Paths in flight per pass.  Fewer, larger passes are faster (every launch of a pass ends in a drain phase, and late bounces
@@ -1365,7 +1394,7 @@ int render_local(cray_ctx* c, cray_scene* s, const cray_render_params* prm, cray
             memset(stats, 0, sizeof(*stats));
             fill_stats(h, stats);
             stats->paths = need;
-            stats->trace_records = (uint32_t)(measuring >= 0 ? measuring * 0x11 : ((prm->count_traversal || prm->precision != CRAY_PRECISION_F64) ? 0 : (s->use_b0 | (s->use_rest << 4))));
+            stats->trace_records = used_records;
             stats->trace_mixed_ms = ms[FAM_MIXED]; stats->trace_mixed_launches = launches[FAM_MIXED];
             stats->trace_closest_ms = ms[FAM_CLOSEST]; stats->trace_any_ms = ms[FAM_ANY];
             stats->shade_ms = ms[FAM_SHADE]; stats->other_ms = ms[FAM_OTHER];
@@ -1513,7 +1542,7 @@ extern "C" int cray_trace(cray_ctx* c, cray_scene* s, const cray_ray* rays, size
     s->hybrid_ok = s->dev.bounds_in_div_range && hyb_scene_ok(s->dev.root_lo, s->dev.root_hi);
     const int level = (c->hybrid > 0 && s->hybrid_ok) ? c->hybrid : 0;
     if ((e = ensure_hybrid(c, s, level))) return e;
-    const bool hyb = level == 1, hyb2 = level == 2;
+    const bool shp = shapes_fit_lds(c, s->dev);   // the timed instantiations the frame loop would launch for this scene
     if (mixed) {
         // k_trace_mixed as the frame loop launches it: positions [0, n) of the virtual queue are the shadow rays of paths
         // 0..n-1 (an identity queue), positions [n, 2n) the path segments of the same paths (tmax = +inf, like Ray::new)
@@ -1523,19 +1552,12 @@ extern "C" int cray_trace(cray_ctx* c, cray_scene* s, const cray_ray* rays, size
         HIP_TRY(hipMemcpy(c->shadow_queue, iota.data(), n * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(&ctr->n_shadow, &cnt, sizeof(cnt), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(&ctr->n_active0, &cnt, sizeof(cnt), hipMemcpyHostToDevice));
-        if (hyb2) hipLaunchKernelGGL(k_trace_mixed<2>, dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow,
-                           (const uint32_t*)nullptr, (const unsigned int*)&ctr->n_active0, ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16) | (c->steal ? 0x8000u : 0u));
-        else if (hyb) hipLaunchKernelGGL(k_trace_mixed<1>, dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow,
-                           (const uint32_t*)nullptr, (const unsigned int*)&ctr->n_active0, ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16) | (c->steal ? 0x8000u : 0u));
-        else hipLaunchKernelGGL(k_trace_mixed<0>, dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow,
-                           (const uint32_t*)nullptr, (const unsigned int*)&ctr->n_active0, ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16) | (c->steal ? 0x8000u : 0u));
+        launch_mixed(level, shp, g, c->stream, s->dev, ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, (const uint32_t*)nullptr,
+                     (const unsigned int*)&ctr->n_active0, ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16) | (c->steal ? 0x8000u : 0u) | (shp ? 0x4000u : 0u));
     } else {
 #define CRAY_TRACE_GO(ANY_, COUNT_, TMAX_)                                                                                       \
-    do {                                                                                                                          \
-        if (hyb2 && !COUNT_) hipLaunchKernelGGL((k_trace<ANY_, false, 2>), dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)nullptr, (const unsigned int*)nullptr, (uint32_t)n, TMAX_, ctr, &ctr->trace_head, c->refill_min | (c->steal ? 0x8000u : 0u)); \
-        else if (hyb) hipLaunchKernelGGL((k_trace<ANY_, COUNT_, 1>), dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)nullptr, (const unsigned int*)nullptr, (uint32_t)n, TMAX_, ctr, &ctr->trace_head, c->refill_min | (c->steal ? 0x8000u : 0u)); \
-        else hipLaunchKernelGGL((k_trace<ANY_, COUNT_, 0>), dim3(g), dim3(kBlock), 0, c->stream, s->dev, ps, (const uint32_t*)nullptr, (const unsigned int*)nullptr, (uint32_t)n, TMAX_, ctr, &ctr->trace_head, c->refill_min | (c->steal ? 0x8000u : 0u)); \
-    } while (0)
+    launch_trace<ANY_, COUNT_>(level, shp, g, c->stream, s->dev, ps, (const uint32_t*)nullptr, (const unsigned int*)nullptr, (uint32_t)n, TMAX_, ctr, \
+                               &ctr->trace_head, c->refill_min | (c->steal ? 0x8000u : 0u) | (shp ? 0x4000u : 0u))
         // closest hit with caller-supplied tmax: rays whose tmax is finite go through the same kernel via stmax
         if (mode == CRAY_TRACE_ANY) CRAY_TRACE_GO(true, true, (const double*)nullptr);
         else if (mode == CRAY_TRACE_ANY_TIMED) CRAY_TRACE_GO(true, false, (const double*)nullptr);

@@ -51,6 +51,7 @@ constexpr int kBlock = 256;
 //  (the shadow rays add to L, the segments write hit records), and together they have one drain phase instead
 //  of two — the lanes of a draining any-hit launch were 84 % idle for a fifth of its iterations.
 enum { kTraceClosest = 0, kTraceAny = 1, kTraceMixed = 2 };
+constexpr uint32_t kTraceLdsShapes = 8;   // sphere + disk records (272 B each) a traversal block stages in LDS
 // the slab summary of a child box the timed and the counting kernels use (cray_math.h): encoded special values by default,
 // -DCRAY_KEY_PLAIN=1 for the +-inf form (A/B builds)
 #ifdef CRAY_KEY_PLAIN
@@ -61,7 +62,8 @@ enum { kTraceClosest = 0, kTraceAny = 1, kTraceMixed = 2 };
 //  HYB        : certified f32 culling (cray_math.h hyb_key): interior nodes are read as 64-B f32 records, every decision the f32
 //               enclosure cannot certify is retaken from the f64 record in a RESOLVE step of the lane.  Same hits, same counters.
 //  HYB = 2    : the same with pair lines (InnerNodeP): the record of the child a lane descends into may already be in its registers.
-template <int MODE, bool COUNT, int HYB>
+//  SHAPES_LDS : the scene's few sphere / disk records are staged in LDS by every block (the host picks this instantiation when they fit).
+template <int MODE, bool COUNT, int HYB, bool SHAPES_LDS = false>
 __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& ps, const uint32_t* __restrict__ queue, const uint32_t n_first,
                                            const uint32_t* __restrict__ queue_b, const uint32_t n_b, const double* __restrict__ closest_tmax,
                                            Counters* ctr, unsigned int* work_head, unsigned int refill_min) {
@@ -106,6 +108,28 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
     // "owner" — the number of workers still walking and whether one of them found an occluder; `steal_pair` matches the k-th idle
     // lane of a wave with its k-th donor.  All three are only ever touched by the lanes of ONE wave (its own 64 entries).
     __shared__ uint32_t grp_cnt[STEAL ? kBlock : 1], grp_occ[STEAL ? kBlock : 1], steal_pair[STEAL ? kBlock : 1];
+    // The sphere / disk records (2 x 16 f64 of transform + 2 radii each: 272 B) of a scene that has only a few of them sit in LDS
+    // for the launch: a lane that reaches such a slot — in 13.5 % of configs[2]'s wave-iterations one does, the ground sphere —
+    // would otherwise make the whole wave wait for a second, dependent fetch from global memory inside the iteration
+    // (CRAY_TRACE_DIAG, profiles/r04_experiments.md: k_trace_mixed 137.0 -> 131.5 ms on f64 records, 131.9 -> 128.9 with f32 culling).
+    // Its own instantiation: through one generic pointer for both cases the scenes that do NOT fit paid 9 % (flat loads).
+    __shared__ double lds_shapes[SHAPES_LDS ? kTraceLdsShapes * (sizeof(cray_xf_shape) / 8) : 1];
+    const cray_xf_shape* spheres = sc.spheres;
+    const cray_xf_shape* disks = sc.disks;
+    // (the host launches this instantiation only when 0 < n_spheres + n_disks <= kTraceLdsShapes, and sets bit 14 of refill_min.
+    // For the f64 instantiations the bit is tested, so that the compiler cannot prove where the records are: with pointers it
+    // KNOWS to be LDS k_trace_mixed<0> came out with two registers spilled in its loop and the gain was gone — 138.0 ms against
+    // 131.4 with this test and 137.1 without any staging, profiles/r04_lds_shapes_ab.log.)
+    if (SHAPES_LDS && (HYB != 0 || (refill_min & 0x4000u) != 0)) {
+        constexpr uint32_t per = sizeof(cray_xf_shape) / 8;
+        const double* gs = reinterpret_cast<const double*>(sc.spheres);
+        const double* gd = reinterpret_cast<const double*>(sc.disks);
+        for (uint32_t i = threadIdx.x; i < sc.n_spheres * per; i += kBlock) lds_shapes[i] = gs[i];
+        for (uint32_t i = threadIdx.x; i < sc.n_disks * per; i += kBlock) lds_shapes[sc.n_spheres * per + i] = gd[i];
+        __syncthreads();
+        spheres = reinterpret_cast<const cray_xf_shape*>(lds_shapes);
+        disks = reinterpret_cast<const cray_xf_shape*>(lds_shapes + sc.n_spheres * per);
+    }
     int sbase = 0;              // bottom of this lane's stack: entries [sbase, sp) are its own, [0, sbase) were given away
     uint32_t owner = tid;       // thread whose grp_cnt / grp_occ entry this lane's ray uses
     bool shared = false;        // this lane's ray has (had) other workers
@@ -209,20 +233,20 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
 #undef CRAY_ANY_LANE
 }
 
-template <bool ANY, bool COUNT, int HYB>
+template <bool ANY, bool COUNT, int HYB, bool SHAPES_LDS = false>
 __global__ void CRAY_TRACE_EU __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace(DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
                                                   const unsigned int* __restrict__ n_ptr, uint32_t n_fixed,
                                                   const double* __restrict__ closest_tmax, Counters* ctr, unsigned int* work_head, unsigned int refill_min) {
-    trace_body<ANY ? kTraceAny : kTraceClosest, COUNT, HYB>(sc, ps, queue, n_ptr ? *n_ptr : n_fixed, nullptr, 0u, closest_tmax, ctr, work_head, refill_min);
+    trace_body<ANY ? kTraceAny : kTraceClosest, COUNT, HYB, SHAPES_LDS>(sc, ps, queue, n_ptr ? *n_ptr : n_fixed, nullptr, 0u, closest_tmax, ctr, work_head, refill_min);
 }
 
 // shadow rays of one bounce (any_queue) + path segments of the next (closest_queue) in one persistent launch
-template <int HYB>
+template <int HYB, bool SHAPES_LDS = false>
 __global__ void CRAY_TRACE_EU __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace_mixed(DevScene sc, PathState ps, const uint32_t* __restrict__ any_queue,
                                                   const unsigned int* __restrict__ n_any_ptr, const uint32_t* __restrict__ closest_queue,
                                                   const unsigned int* __restrict__ n_closest_ptr, Counters* ctr, unsigned int* work_head,
                                                   unsigned int refill_min) {
-    trace_body<kTraceMixed, false, HYB>(sc, ps, any_queue, *n_any_ptr, closest_queue, *n_closest_ptr, nullptr, ctr, work_head, refill_min);
+    trace_body<kTraceMixed, false, HYB, SHAPES_LDS>(sc, ps, any_queue, *n_any_ptr, closest_queue, *n_closest_ptr, nullptr, ctr, work_head, refill_min);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -14,6 +14,20 @@ cd "$root"
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
+# The library times a scene's first two frames to choose the records its traversal launches read (f64 or certified f32 culling, per
+# launch kind): a plain bench run first says what it chose; every profiled pass below is PINNED to that choice, so that the one frame
+# of a counter pass and the timed frames of the stats pass run the steady-state kernels and nothing else.
+python3 bench.py --workload $wl --steps 2 --warmup 2 --cpu-baseline 0 --count-pass 0 > $out/choice.log 2> /dev/null
+pin=$(python3 - "$out/choice.log" <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read())
+r = d['kernel_ms_per_step']['trace_records']
+v = lambda n: '1' if n.startswith('certified') else '0'
+print('CRAY_RECORDS_B0=%s CRAY_RECORDS_REST=%s' % (v(r['bounce0']), v(r['other_launches'])))
+PY
+)
+echo "records pinned for the profiled passes: $pin" | tee $out/pin.txt
+export $pin
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o run -- python3 bench.py --workload $wl --steps 3 --warmup 1 --cpu-baseline 0 > $out/bench.log 2> $out/stats.log
 cp $(find $out/stats -name '*kernel_stats.csv' | head -1) $out/kernel_stats.csv
 for pass in "fetch_size:FETCH_SIZE" "write_size:WRITE_SIZE" "sq:SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU" "tcc:TCC_HIT_sum TCC_MISS_sum" "ta:TA_TA_BUSY_sum GRBM_GUI_ACTIVE" "tcp:TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do

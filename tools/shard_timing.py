@@ -38,7 +38,7 @@ def main():
     base = None
     for world in [int(w) for w in args.worlds.split(',')]:
         per_rank = []
-        for rank in ([int(r) for r in args.ranks.split(',')] if args.ranks else range(world)):
+        for rank in ([int(r) for r in args.ranks.split(',') if int(r) < world] if args.ranks else range(world)):
             best = None
             for _ in range(args.reps):
                 torch.cuda.synchronize()
