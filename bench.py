@@ -359,12 +359,15 @@ def main():
         else:   # traversal counting frames and max_depth 1 have no mixed launches: the family is the dominant kernel
             roofline = block('k_trace family (k_trace<closest> + k_trace<any>)', fam_ms, fam_launches, traffic_frame, alg_family, traced)
         roofline['bound'] = 'hbm'
-        # `bound` can only say "hbm" or "mfma" (the bench contract); the unit this kernel actually sits on, from the counters
-        # of the profiled build (other_bounds): L1 line fills per CU at the rate a CU can keep in flight
-        roofline['binding_unit'] = 'l1_fill'
+        # `bound` can only say "hbm" or "mfma" (the bench contract).  What the kernel's time follows, from the counters of the
+        # profiled build (other_bounds) and the round-4 pair-line experiment (27 % fewer L1 line fills, 9 % more
+        # VALU instructions, 17 % more time): VALU issue, with the per-CU L1 fill rate and the texture addresser as co-limits
+        roofline['binding_unit'] = 'valu_issue'
+        roofline['co_limits'] = ['valu_issue', 'l1_fill', 'texture_addresser']
         roofline['traffic_provenance'] = provenance
         roofline['bound_note'] = ('HBM is the roofline the north star prices this path against; the counters of the same build say what binds the kernel '
-                                  'is per CU: L1 line fills at the rate a CU can keep in flight, texture addresser and f64 VALU issue at ~0.7 each: other_bounds')
+                                  'is per CU: VALU issue first (the time follows the instruction count, DESIGN.md 3.4), L1 line fills and the texture addresser '
+                                  'as co-limits: other_bounds')
         if traffic_frame and ent.get('units'):
             # utilisations of the units that do bind the path, from the SQ / TA / TCC / TCP passes of the same profiled build
             u = ent['units']
