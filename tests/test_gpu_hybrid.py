@@ -120,6 +120,47 @@ def test_a_context_that_chooses_its_records_per_scene_renders_the_same_film():
     ctx.close()
 
 
+@pytest.mark.parametrize('records', ['0', '1'])
+def test_shape_records_in_lds_or_in_global_memory_same_film(records):
+    """The traversal blocks stage a scene's sphere / disk records in LDS when there are at most eight of them (their own
+    instantiations); a scene with more, or CRAY_LDS_SHAPES=0, reads them from global memory.  Same hits either way:
+    films of both contexts equal the oracle's, on a scene that fits (two disks, one sphere) and on one that does not (twelve
+    spheres and a disk light), with f64 records and with certified f32 culling."""
+    import os
+    from craytracer_amd import scene as S, scenes
+    old = {k: os.environ.get(k) for k in ('CRAY_LDS_SHAPES', 'CRAY_HYBRID')}
+    os.environ['CRAY_HYBRID'] = records
+    try:
+        os.environ['CRAY_LDS_SHAPES'] = '1'
+        staged = backend.Context(0)
+        os.environ['CRAY_LDS_SHAPES'] = '0'
+        plain = backend.Context(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    cam = S.Camera.perspective(S.Film(96, 64), (0, 3, -9), (0, 1, 4), (0, 1, 0), 40)
+    matte = S.Material.new_matte(S.Color(0.7, 0.6, 0.5), 0.0)
+    glass = S.Material.new_glass(S.Color(1, 1, 1), S.Color(0.8, 0.8, 0.8), 1.5)
+    light = S.Shape.new_disk((0, 8, 4), 90, 0, 2.5, 0)
+    prims = [S.Primitive.new(S.Shape.new_disk((0, 0, 4), 90, 0, 30, 0), matte),
+             S.Primitive.new_area_light(light, S.Light.Area(light, S.Color(12, 11, 9)))]
+    for i in range(12):
+        prims.append(S.Primitive.new(S.Shape.new_sphere((-5.5 + i, 0.45 + 0.3 * (i % 3), 2.0 + 0.5 * (i % 4)), 0.45), glass if i % 2 else matte))
+    many = S.Scene(5, 8, cam, [S.Light.Infinite(S.Color(0.05, 0.07, 0.1))], prims)
+    for sc in (scenes.simple(64, 48, 8, 4), many):
+        ref, _ = ol.OracleScene(sc).render(seed=6)
+        for ctx in (staged, plain):
+            dev = ctx.upload(backend.HostScene(sc))
+            f, st = dev.render(seed=6)
+            assert st['trace_records'] == int(records) * 0x11
+            assert np.array_equal(f, ref)
+            dev.close()
+    staged.close(); plain.close()
+
+
 @pytest.mark.parametrize('name', ['test', 'staircase', 'dragon'])
 def test_shading_tables_in_lds_or_in_global_memory_same_film(name):
     """k_shade has two instantiations: the small shading tables staged in LDS (when they fit) or read from global memory
