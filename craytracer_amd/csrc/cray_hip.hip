@@ -10,6 +10,7 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -85,6 +86,15 @@ struct cray_ctx {
     Counters* counters = nullptr;
     uint32_t* pix_list = nullptr;
     size_t pix_capacity = 0;
+    // the same pixels in the order they are RENDERED: the rank's tiles sorted by the cost of their camera rays, most expensive
+    // first (ensure_tile_order, k_tile_probe).  pix_list stays the canonical order the gather packs and sends in.
+    uint32_t* pix_render = nullptr;
+    size_t pix_render_capacity = 0;
+    const uint32_t* pix_order = nullptr;          // what run_pass reads: pix_render or pix_list
+    const void* order_scene = nullptr;            // the scene and pixel list pix_render was computed for
+    uint64_t order_key[6] = {0, 0, 0, 0, 0, 0};
+    bool order_valid = false;
+    int tile_order = 1;                           // CRAY_TILE_ORDER=0: render in the canonical tile order
     uint64_t pix_key[6] = {0, 0, 0, 0, 0, 0};  // (W, H, tile w, tile h, rank, world) of the list in pix_list
     size_t pix_count = 0;
     bool pix_count_valid = false;
@@ -350,6 +360,7 @@ extern "C" int cray_ctx_create(int device_id, void* stream, cray_ctx** out) {
     c->refill_min_any = (unsigned int)env_int("CRAY_REFILL_MIN_ANY", 1, 64, (int)c->refill_min_any);
     c->steal = (unsigned int)env_int("CRAY_STEAL", 0, 1, (int)c->steal);
     c->lds_shapes = (unsigned int)env_int("CRAY_LDS_SHAPES", 0, 1, (int)c->lds_shapes);
+    c->tile_order = env_int("CRAY_TILE_ORDER", 0, 1, c->tile_order);
     c->trace_blocks_per_cu = env_int("CRAY_TRACE_BLOCKS_PER_CU", 1, 16, c->trace_blocks_per_cu);
     c->shade_blocks_per_cu = env_int("CRAY_SHADE_BLOCKS_PER_CU", 0, 64, c->shade_blocks_per_cu);
     c->trace32_blocks_per_cu = env_int("CRAY_TRACE32_BLOCKS_PER_CU", 1, 16, c->trace32_blocks_per_cu);
@@ -365,6 +376,7 @@ extern "C" void cray_ctx_destroy(cray_ctx* c) {
     if (c->deep_ref) (void)hipFree(c->deep_ref);
     if (c->deep_key) (void)hipFree(c->deep_key);
     if (c->pix_list) (void)hipFree(c->pix_list);
+    if (c->pix_render) (void)hipFree(c->pix_render);
     if (c->film) (void)hipFree(c->film);
     if (c->out_stage) (void)hipFree(c->out_stage);
     comm_release(c);
@@ -1141,7 +1153,7 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
     const uint32_t independent = prm.sampler == CRAY_SAMPLER_INDEPENDENT ? 1u : 0u;
     const int mode = (prm.integrator == CRAY_INTEGRATOR_SIMPLE ? kModeSimple : 0) | (uni_nx ? kModeUniform : 0) | (independent ? kModeIndependent : 0);
     static const int occ_raygen = resident_blocks(reinterpret_cast<const void*>(&k_raygen), kBlock, 4);
-    hipLaunchKernelGGL(k_raygen, dim3(grid_for(c, n_paths, 4 * occ_raygen)), dim3(kBlock), 0, st, d, c->ps, c->pix_list, pp.px0, n_paths, spp_pass, pp.s_lo, prm.seed, uni_nx, uni_ny, independent);
+    hipLaunchKernelGGL(k_raygen, dim3(grid_for(c, n_paths, 4 * occ_raygen)), dim3(kBlock), 0, st, d, c->ps, c->pix_order, pp.px0, n_paths, spp_pass, pp.s_lo, prm.seed, uni_nx, uni_ny, independent);
     if (tm) { int e = tm->end(); if (e) return e; }
 
     // Launch sequence of a pass.  The shadow rays of bounce b and the path segments of bounce b+1 both depend on
@@ -1180,7 +1192,7 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
         HIP_TRY(hipMemsetAsync(((b + 1) & 1) ? &ctr->n_shadow : &ctr->n_active0, 0, 4 * sizeof(unsigned int), st));
         if (tm) { int e = tm->begin(FAM_SHADE); if (e) return e; }
         ShadeLaunch<0>::go(s->shade_variant, mode, d.shade_tables_bytes != 0, c, (size_t)n_paths, st, d, ps_b, ps_n, q, nq, n_paths, b, spp_pass, pp.s_lo, q_next, n_next,
-                           c->shadow_queue, &ctr->n_shadow, ctr, trace_all, uni_nx, uni_ny, (const uint32_t*)c->pix_list, pp.px0, prm.seed);
+                           c->shadow_queue, &ctr->n_shadow, ctr, trace_all, uni_nx, uni_ny, c->pix_order, pp.px0, prm.seed);
         if (tm) { int e = tm->end(); if (e) return e; }
 
         if (mixed && b + 1 < d.max_depth) {
@@ -1219,7 +1231,7 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
         static const int occ_film = resident_blocks(reinterpret_cast<const void*>(&k_film), 64, 16);
         const size_t groups = ((size_t)pp.n_pix + 63) / 64, cap = (size_t)c->n_cu * occ_film * 2;  // one wave per block
         const int g_film = (int)(groups < cap ? (groups ? groups : 1) : cap);
-        hipLaunchKernelGGL(k_film, dim3(g_film), dim3(64), 0, st, c->ps, c->pix_list, pp.px0, pp.n_pix, spp_pass, pp.s_lo,
+        hipLaunchKernelGGL(k_film, dim3(g_film), dim3(64), 0, st, c->ps, c->pix_order, pp.px0, pp.n_pix, spp_pass, pp.s_lo,
                            prm.sample_batch, c->film, ctr);
     }
     if (tm) { int e = tm->end(); if (e) return e; }
@@ -1313,6 +1325,63 @@ int ensure_pix_list(cray_ctx* c, uint32_t W, uint32_t H, const cray_render_param
     memcpy(c->pix_key, pix_key, sizeof(pix_key));
     c->pix_count = pix.size();
     c->pix_count_valid = true;
+    c->order_valid = false;
+    return CRAY_OK;
+}
+
+// The rank's tiles in the order of their cost (k_tile_probe), most expensive first: the pixel list the kernels of a frame read
+// (c->pix_order).  Computed once per (scene, pixel list) — ~1 ms: a probe launch, 8 bytes per tile to the host, a sort, the
+// permuted list back — and kept; frames too small for a tail to matter and lists of few tiles render in the canonical order.
+int ensure_tile_order(cray_ctx* c, cray_scene* s, const cray_render_params& prm, size_t n_paths) {
+    c->pix_order = c->pix_list;
+    const uint32_t W = s->dev.film_w, H = s->dev.film_h;
+    if (!c->tile_order || n_paths < ((size_t)1 << 21) || s->dev.n_inner == 0) return CRAY_OK;
+    if (c->order_valid && c->order_scene == (const void*)s && memcmp(c->order_key, c->pix_key, sizeof(c->order_key)) == 0) { c->pix_order = c->pix_render; return CRAY_OK; }
+    c->order_valid = false;
+    try {
+        // the rank's tiles, as rank_pixels walks them
+        std::vector<uint32_t> rect, start;
+        const uint64_t tw = prm.tile_width, th = prm.tile_height;
+        const uint64_t tiles_x = (W + tw - 1) / tw, tiles_y = (H + th - 1) / th;
+        uint64_t at = 0;
+        for (uint64_t t = prm.rank; t < tiles_x * tiles_y; t += prm.world_size) {
+            const uint64_t tx = (t % tiles_x) * tw, ty = (t / tiles_x) * th;
+            const uint64_t x1 = tx + tw < W ? tx + tw : W, y1 = ty + th < H ? ty + th : H;
+            rect.push_back((uint32_t)tx); rect.push_back((uint32_t)ty); rect.push_back((uint32_t)(x1 - tx)); rect.push_back((uint32_t)(y1 - ty));
+            start.push_back((uint32_t)at);
+            at += (x1 - tx) * (y1 - ty);
+        }
+        const size_t n_tiles = start.size();
+        if (n_tiles < 64 || at != c->pix_count) return CRAY_OK;
+        start.push_back((uint32_t)at);
+        DevMem mem;
+        uint32_t* d_rect;
+        unsigned long long* d_cost;
+        HIP_TRY(mem.get(&d_rect, rect.size()));
+        HIP_TRY(mem.get(&d_cost, n_tiles));
+        HIP_TRY(hipMemcpyAsync(d_rect, rect.data(), rect.size() * 4, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_tile_probe, dim3((unsigned int)n_tiles), dim3(64), 0, c->stream, s->dev, (const uint32_t*)d_rect, (uint32_t)n_tiles, d_cost);
+        std::vector<unsigned long long> cost(n_tiles);
+        HIP_TRY(hipMemcpyAsync(cost.data(), d_cost, n_tiles * 8, hipMemcpyDeviceToHost, c->stream));
+        std::vector<uint32_t> canon(c->pix_count);
+        HIP_TRY(hipMemcpyAsync(canon.data(), c->pix_list, c->pix_count * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipGetLastError());
+        std::vector<uint32_t> idx(n_tiles);
+        for (size_t i = 0; i < n_tiles; i++) idx[i] = (uint32_t)i;
+        std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+        std::vector<uint32_t> out;
+        out.reserve(c->pix_count);
+        for (uint32_t i : idx) out.insert(out.end(), canon.begin() + start[i], canon.begin() + start[i + 1]);
+        int e = ensure_buffer(&c->pix_render, &c->pix_render_capacity, out.size());
+        if (e) return e;
+        HIP_TRY(hipMemcpyAsync(c->pix_render, out.data(), out.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));   // `out` is a local vector
+    } catch (const std::exception& ex) { set_last_error("tile order: %s", ex.what()); return CRAY_ERR_INVALID; }
+    c->order_scene = (const void*)s;
+    memcpy(c->order_key, c->pix_key, sizeof(c->order_key));
+    c->order_valid = true;
+    c->pix_order = c->pix_render;
     return CRAY_OK;
 }
 
@@ -1333,6 +1402,7 @@ int render_local(cray_ctx* c, cray_scene* s, const cray_render_params* prm, cray
     if ((e = choose_trace_records(c, s, prm->count_traversal != 0 || prm->precision != CRAY_PRECISION_F64,
                                   n_pix_rank * (size_t)(s_end > s_begin ? s_end - s_begin : 0), &measuring))) return e;
     const uint32_t used_records = (uint32_t)(s->use_b0 | (s->use_rest << 4));   // what THIS call's launches read (cray_stats.trace_records)
+    if ((e = ensure_tile_order(c, s, *prm, n_pix_rank * (size_t)(s_end > s_begin ? s_end - s_begin : 0)))) return e;
     const size_t film_floats = (size_t)W * H * 3;
     if ((e = ensure_buffer(&c->film, &c->film_floats, film_floats))) return e;
     // Paths in flight per pass.  Fewer, larger passes are faster (every launch of a pass ends in a drain phase, and late bounces
@@ -1485,6 +1555,8 @@ extern "C" int cray_render_samples(cray_ctx* c, cray_scene* s, const cray_render
     cray_render_params p2 = *prm;
     p2.sample_batch = n > p2.sample_batch ? n : p2.sample_batch;
     PassPlan pp{0, (uint32_t)n_pix, s_begin, s_end};
+    c->pix_order = c->pix_list;
+    c->order_valid = false;
     if ((e = run_pass(c, s, p2, pp, nullptr))) return e;
     HIP_TRY(hipStreamSynchronize(c->stream));
     std::vector<double> r(n_pix * n), g(n_pix * n), b(n_pix * n);

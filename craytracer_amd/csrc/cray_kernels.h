@@ -534,6 +534,74 @@ __global__ void __launch_bounds__(kBlock) k_make_slots32(const LeafSlot* __restr
     out[i] = o;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Tile cost probe (round 4): the bounce-0 launch ends when its slowest pixels end, and a pixel whose camera rays graze the
+// mesh needs ten times the node visits of one that looks at the sky.  Started last, such a pixel is the tail of the launch
+// (1.0-1.8 ms of an eighth of configs[2]); started first it is hidden behind everything else.  One wave per tile of a rank's
+// list walks 64 probe rays (an 8 x 8 grid of pixel centres) through the tree the way a camera ray would and reports
+// max << 32 | sum of the probes' node visits + primitive tests; the host orders the rank's tiles by it, most expensive
+// first (ensure_tile_order).  A scheduling hint only: which order the pixels are rendered in enters no result — the probe
+// need not (and does not) reproduce the reference's traversal bit for bit, it uses the plain slab test and a 64-entry stack.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_tile_probe(DevScene sc, const uint32_t* __restrict__ rect /* [n][4]: x0, y0, w, h */, uint32_t n_tiles,
+                                                   unsigned long long* __restrict__ cost) {
+    const uint32_t t = blockIdx.x;
+    if (t >= n_tiles) return;
+    const uint32_t lane = threadIdx.x, gx = lane & 7u, gy = lane >> 3;
+    const uint32_t x0 = rect[4 * t], y0 = rect[4 * t + 1], w = rect[4 * t + 2], h = rect[4 * t + 3];
+    uint32_t px = x0 + ((2u * gx + 1u) * w) / 16u, py = y0 + ((2u * gy + 1u) * h) / 16u;
+    px = px < x0 + w ? px : x0 + w - 1u; py = py < y0 + h ? py : y0 + h - 1u;
+    ray_t ray = camera_ray(sc, 0.5, 0.5, 0.5, 0.5, px, py);
+    uint32_t stack[64];
+    double keys[64];
+    int sp = 0;
+    uint32_t cur = sc.root_ref, visits = 0;
+    bool go = child_key(sc.root_lo, sc.root_hi, ray.o, ray.d) < ray.tmax;
+    while (go) {
+        bool pop = true;
+        if (!ref_is_leaf(cur)) {
+            const InnerNode& nd = sc.inner[cur];
+            visits++;
+            const double k0 = child_key(nd.lo0, nd.hi0, ray.o, ray.d), k1 = child_key(nd.lo1, nd.hi1, ray.o, ray.d);
+            const bool right_first = comp(ray.d, (int)nd.axis) < 0.0;
+            const uint32_t near = right_first ? nd.ref1 : nd.ref0, far = right_first ? nd.ref0 : nd.ref1;
+            const double kn = right_first ? k1 : k0, kf = right_first ? k0 : k1;
+            const bool an = kn < ray.tmax, af = kf < ray.tmax;
+            if (an) {
+                if (af && sp < 64) { stack[sp] = far; keys[sp] = kf; sp++; }
+                cur = near; pop = false;
+            } else if (af) { cur = far; pop = false; }
+        } else {
+            const uint32_t first = ref_leaf_first(cur), cnt = ref_leaf_count(cur);
+            for (uint32_t i = 0; i < cnt; i++) {
+                const LeafSlot& sl = sc.slots[first + i];
+                visits++;
+                if (sl.kind == CRAY_SHAPE_TRIANGLE) {
+                    double tt, uu, vv;
+                    if (tri_test(mk(sl.v0[0], sl.v0[1], sl.v0[2]), mk(sl.e1[0], sl.e1[1], sl.e1[2]), mk(sl.e2[0], sl.e2[1], sl.e2[2]), ray, tt, uu, vv)) ray.tmax = tt;
+                } else {
+                    const uint32_t shp = (uint32_t)__double2loint(sl.v0[0]);
+                    if (sl.kind == CRAY_SHAPE_SPHERE) (void)sphere_hit(sc.spheres[shp], ray, false, nullptr);
+                    else (void)disk_hit(sc.disks[shp], ray, false, nullptr);
+                }
+            }
+        }
+        if (pop) {
+            for (;;) {
+                if (sp == 0) { go = false; break; }
+                --sp;
+                if (keys[sp] < ray.tmax) { cur = stack[sp]; break; }
+            }
+        }
+    }
+    uint32_t mx = visits, sum = visits;
+    for (int o = 32; o; o >>= 1) {
+        const uint32_t a = (uint32_t)__shfl_xor((int)mx, o), b = (uint32_t)__shfl_xor((int)sum, o);
+        mx = a > mx ? a : mx; sum += b;
+    }
+    if (lane == 0) cost[t] = ((unsigned long long)mx << 32) | (unsigned long long)sum;
+}
+
 // render_pixel up to the camera ray (craytracer.rs:148-156) for every path of a pass.
 // path p -> pixel pix_list[px0 + p / spp_pass], sample s_lo + p % spp_pass.  (Sample-major order was
 // measured: k_film gets trivially coalesced, but the traversal and k_shade lose the coherence of the 16
