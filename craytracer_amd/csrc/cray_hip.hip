@@ -59,6 +59,10 @@ struct cray_ctx {
     // idle lanes a wave waits for before it fetches new rays: the coherent camera rays of bounce 0 finish together (late refills
     // cost little and keep neighbouring pixels in one wave), the incoherent later bounces refill earlier (profiles/r02_experiments.md)
     unsigned int refill_min = 28, refill_min_b0 = 64, refill_min_any = 28;
+    // the launches that read certified f32 culling refill a little earlier (their iteration is shorter, an idle lane costs relatively
+    // more): 20 / 20 is 1 % faster than 28 / 28 on configs[2]; the f64 launches of configs[3] lose 2 % at 20 / 20
+    // (profiles/r04_refill_sweep_f32_culling*.log)
+    unsigned int refill_min_hyb = 20, refill_min_any_hyb = 20;
     unsigned int lds_shapes = 1;   // the few sphere / disk records of a scene staged in LDS by the traversal launches (CRAY_LDS_SHAPES=0: read global memory)
     unsigned int steal = 1;   // work sharing among the lanes of a wave in the drain of the shadow-ray launches (trace_body, STEAL); CRAY_STEAL=0 turns it off
     int trace_blocks_per_cu = 4;
@@ -358,6 +362,9 @@ extern "C" int cray_ctx_create(int device_id, void* stream, cray_ctx** out) {
     c->refill_min = (unsigned int)env_int("CRAY_REFILL_MIN", 1, 64, (int)c->refill_min);
     c->refill_min_b0 = (unsigned int)env_int("CRAY_REFILL_MIN_B0", 1, 64, (int)c->refill_min_b0);
     c->refill_min_any = (unsigned int)env_int("CRAY_REFILL_MIN_ANY", 1, 64, (int)c->refill_min_any);
+    // (an explicit CRAY_REFILL_MIN / _ANY applies to both kinds of launches: the sweeps set those)
+    c->refill_min_hyb = (unsigned int)env_int("CRAY_REFILL_MIN", 1, 64, (int)c->refill_min_hyb);
+    c->refill_min_any_hyb = (unsigned int)env_int("CRAY_REFILL_MIN_ANY", 1, 64, (int)c->refill_min_any_hyb);
     c->steal = (unsigned int)env_int("CRAY_STEAL", 0, 1, (int)c->steal);
     c->lds_shapes = (unsigned int)env_int("CRAY_LDS_SHAPES", 0, 1, (int)c->lds_shapes);
     c->tile_order = env_int("CRAY_TILE_ORDER", 0, 1, c->tile_order);
@@ -1200,7 +1207,8 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
             if (fast) hipLaunchKernelGGL((k_trace32<kTraceMixed>), dim3(g_trace32), dim3(kBlock), 0, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, 0u,
                                          (const uint32_t*)q_next, (const unsigned int*)n_next, ctr, &ctr->trace_head, c->refill_min, 0u);
             else launch_mixed(s->use_rest, shp, g_trace, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, (const uint32_t*)q_next,
-                              (const unsigned int*)n_next, ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16) | (c->steal ? 0x8000u : 0u) | shp_bit);
+                              (const unsigned int*)n_next, ctr, &ctr->trace_head,
+                              (s->use_rest ? c->refill_min_hyb | (c->refill_min_any_hyb << 16) : c->refill_min | (c->refill_min_any << 16)) | (c->steal ? 0x8000u : 0u) | shp_bit);
             if (tm) { int e = tm->end(); if (e) return e; }
         } else {
             if (tm) { int e = tm->begin(FAM_ANY); if (e) return e; }
