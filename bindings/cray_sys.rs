@@ -353,7 +353,7 @@ pub struct CrayStats {
     pub trace_records: u32,
     pub trace_mixed_ms: f64,
     pub trace_mixed_launches: u32,
-    pub pad2_: u32,
+    pub tail_split: u32,
     pub closest_hits: u64,
 }
 

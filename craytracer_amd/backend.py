@@ -33,7 +33,7 @@ class Stats(C.Structure):
                  'shadow_prims', 'closest_tri_tests', 'shadow_tri_tests', 'nonfinite', 'stack_overflow')] + \
                [(n, C.c_double) for n in ('seconds', 'trace_closest_ms', 'trace_any_ms', 'shade_ms', 'other_ms')] + \
                [(n, C.c_uint32) for n in ('trace_closest_launches', 'trace_any_launches', 'shade_launches', 'trace_records')] + \
-               [('trace_mixed_ms', C.c_double), ('trace_mixed_launches', C.c_uint32), ('pad2_', C.c_uint32),
+               [('trace_mixed_ms', C.c_double), ('trace_mixed_launches', C.c_uint32), ('tail_split', C.c_uint32),
                 ('closest_hits', C.c_uint64)]
 
     def as_dict(self):

@@ -177,12 +177,19 @@ struct Counters {
     // The words a bounce zeroes sit between the two queue lengths, so that ONE 16-byte memset does it for either parity:
     // bounce b zeroes n_active[(b + 1) & 1] (the queue k_shade fills), n_shadow, trace_head and shade_head, and keeps n_active[b & 1].
     unsigned int n_active0, n_shadow, trace_head, shade_head, n_active1, pad_head_;
+    unsigned long long tail_helped, tail_again;   // small launches: parts of closest-hit rays walked by helpers; rays walked again alone
     unsigned long long diag[32];  // k_trace lane-occupancy diagnostics (CRAY_TRACE_DIAG builds only)
     // Third level of the traversal stack (LDS -> scratch -> here): entries kStackDepth.. of every lane, in global
     // memory as [entry][global thread].  Allocated by the runtime only after a frame overflowed the first two levels.
     uint32_t* deep_ref;
     double* deep_key;
-    unsigned int deep_depth, deep_pad;
+    unsigned int deep_depth;
+    // Small launches (round 4, trace_body TAIL): a mixed launch of fewer than tail_rays rays (0: never) is traced by the
+    // instantiation that lets idle lanes take over parts of unfinished rays of BOTH kinds; tail_res holds what the helpers of a
+    // closest-hit ray found: [global thread of the ray's lane][kTailSlots][t, u, v, primitive | certified << 32].
+    unsigned int tail_rays;
+    double* tail_res;
 };
+constexpr uint32_t kTailSlots = 4;   // helpers one closest-hit ray can have had by the time it ends
 
 }  // namespace cray

@@ -76,6 +76,13 @@ struct cray_ctx {
     uint32_t* queue[2] = {nullptr, nullptr};
     uint32_t* shadow_queue = nullptr;
     // third stack level (Counters::deep_*), allocated after a frame overflowed LDS + scratch
+    double* tail_res = nullptr;     // results of the helpers of closest-hit rays in small mixed launches (trace_body TAIL)
+    unsigned int tail_seg = 1;      // CRAY_TAIL_SEG=0: the small-launch instantiation shares shadow rays only
+    unsigned int tail_age = 16;     // CRAY_TAIL_AGE: a segment hands parts out only after 4 x this many iterations (long rays only)
+    // mixed launches below this many rays run in the TAIL instantiation (CRAY_TAIL_RAYS); 0 = never, the default: exact and
+    // tested, but as measured it costs more than it gives (the f64 instantiation is slower than the f32-culling one
+    // it replaces, and a helper's winning hit near the ray's origin is often uncertifiable, which walks the ray twice)
+    unsigned int tail_rays = 0;
     uint32_t* deep_ref = nullptr;
     double* deep_key = nullptr;
     unsigned int deep_depth = 0;
@@ -210,11 +217,26 @@ int ensure_state(cray_ctx* c, size_t capacity) {
 // zero the device counters, keeping the description of the third stack level
 int reset_counters(cray_ctx* c) {
     HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(Counters), c->stream));
-    if (c->deep_depth) {
-        struct { uint32_t* r; double* k; unsigned int d, pad; } v{c->deep_ref, c->deep_key, c->deep_depth, 0u};
-        static_assert(sizeof(v) == sizeof(Counters) - offsetof(Counters, deep_ref), "deep_* are the tail of Counters");
+    if (c->deep_depth || c->tail_res) {
+        struct { uint32_t* r; double* k; unsigned int d, tail_rays; double* tail_res; } v{c->deep_ref, c->deep_key, c->deep_depth, c->tail_res ? (c->tail_rays | (c->tail_age << 24)) : 0u, c->tail_res};
+        static_assert(sizeof(v) == sizeof(Counters) - offsetof(Counters, deep_ref), "deep_* and tail_* are the tail of Counters");
         HIP_TRY(hipMemcpyAsync(&c->counters->deep_ref, &v, sizeof(v), hipMemcpyHostToDevice, c->stream));
     }
+    return CRAY_OK;
+}
+
+// The result table of the small-launch instantiation (trace_body TAIL): kTailSlots x 4 doubles per thread of the largest
+// traversal grid.  Bit 30 of a child reference must be free for its helpers' bookkeeping: scenes beyond 2^27 leaf slots or
+// 2^30 nodes (and CRAY_TAIL_RAYS=0) run every mixed launch in the ordinary instantiation.
+int ensure_tail(cray_ctx* c, const cray_scene* s) {
+    const bool want = c->tail_rays != 0 && c->steal && c->mix_trace && s->n_slots < (1u << 27) && s->dev.n_inner < (1u << 30);
+    if (!want) {
+        if (c->tail_res) { (void)hipFree(c->tail_res); c->tail_res = nullptr; }
+        return CRAY_OK;
+    }
+    if (c->tail_res) return CRAY_OK;
+    const size_t threads = (size_t)c->n_cu * (size_t)(c->trace_blocks_per_cu > 8 ? c->trace_blocks_per_cu : 8) * kBlock;
+    HIP_TRY(hipMalloc((void**)&c->tail_res, threads * kTailSlots * 4 * sizeof(double)));
     return CRAY_OK;
 }
 
@@ -287,6 +309,7 @@ void fill_stats(const Counters& h, cray_stats* st) {
     st->shadow_nodes = h.shadow_nodes; st->shadow_prims = h.shadow_prims;
     st->closest_tri_tests = h.closest_tri; st->shadow_tri_tests = h.shadow_tri;
     st->nonfinite = h.nonfinite; st->stack_overflow = h.stack_overflow; st->closest_hits = h.closest_hits;
+    st->tail_split = (uint32_t)(h.tail_helped > 0xffffffull ? 0xffffffull : h.tail_helped) | ((uint32_t)(h.tail_again > 255ull ? 255ull : h.tail_again) << 24);
 #ifdef CRAY_TRACE_DIAG
     for (int a = 0; a < 2; a++) {
         const unsigned long long* g = h.diag + 16 * a;
@@ -368,6 +391,9 @@ extern "C" int cray_ctx_create(int device_id, void* stream, cray_ctx** out) {
     c->steal = (unsigned int)env_int("CRAY_STEAL", 0, 1, (int)c->steal);
     c->lds_shapes = (unsigned int)env_int("CRAY_LDS_SHAPES", 0, 1, (int)c->lds_shapes);
     c->tile_order = env_int("CRAY_TILE_ORDER", 0, 1, c->tile_order);
+    c->tail_rays = (unsigned int)env_int("CRAY_TAIL_RAYS", 0, (1 << 24) - 1, (int)c->tail_rays);
+    c->tail_seg = (unsigned int)env_int("CRAY_TAIL_SEG", 0, 1, (int)c->tail_seg);
+    c->tail_age = (unsigned int)env_int("CRAY_TAIL_AGE", 0, 255, (int)c->tail_age);
     c->trace_blocks_per_cu = env_int("CRAY_TRACE_BLOCKS_PER_CU", 1, 16, c->trace_blocks_per_cu);
     c->shade_blocks_per_cu = env_int("CRAY_SHADE_BLOCKS_PER_CU", 0, 64, c->shade_blocks_per_cu);
     c->trace32_blocks_per_cu = env_int("CRAY_TRACE32_BLOCKS_PER_CU", 1, 16, c->trace32_blocks_per_cu);
@@ -381,6 +407,7 @@ extern "C" void cray_ctx_destroy(cray_ctx* c) {
     for (void* p : c->state_allocs) (void)hipFree(p);
     if (c->counters) (void)hipFree(c->counters);
     if (c->deep_ref) (void)hipFree(c->deep_ref);
+    if (c->tail_res) (void)hipFree(c->tail_res);
     if (c->deep_key) (void)hipFree(c->deep_key);
     if (c->pix_list) (void)hipFree(c->pix_list);
     if (c->pix_render) (void)hipFree(c->pix_render);
@@ -1135,8 +1162,14 @@ void launch_trace(int v, bool shp, int grid, hipStream_t st, A... a) {
     }
 }
 template <class... A>
-void launch_mixed(int v, bool shp, int grid, hipStream_t st, A... a) {
+void launch_mixed(int v, bool shp, bool tail, int grid, hipStream_t st, A... a) {
     const dim3 g(grid), b(kBlock);
+    // a mixed launch is launched twice when the small-launch instantiation is on (Counters::tail_rays != 0): each of the two
+    // returns at once unless the launch has its size — the host does not know the queue lengths
+    if (tail) {
+        if (shp) hipLaunchKernelGGL((k_trace_mixed<0, true, true>), g, b, 0, st, a...);
+        else hipLaunchKernelGGL((k_trace_mixed<0, false, true>), g, b, 0, st, a...);
+    }
     if (v == 2) hipLaunchKernelGGL(k_trace_mixed<2>, g, b, 0, st, a...);
     else if (v == 1 && shp) hipLaunchKernelGGL((k_trace_mixed<1, true>), g, b, 0, st, a...);
     else if (v == 1) hipLaunchKernelGGL(k_trace_mixed<1>, g, b, 0, st, a...);
@@ -1169,7 +1202,7 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
     const bool mixed = !count && c->mix_trace;
     const bool fast = prm.precision == CRAY_PRECISION_F32_TRAVERSAL;   // check_render_args refuses it together with counting
     const bool shp = shapes_fit_lds(c, d);
-    const unsigned int shp_bit = shp ? 0x4000u : 0u;
+    const unsigned int shp_bit = (shp ? 0x4000u : 0u) | (c->tail_seg ? 0x2000u : 0u);   // + whether small launches split segments: both ride in refill_min
     const unsigned int trace_all = prm.count_traversal == 1 ? 1u : 0u;  // 2 = count, but keep skipping zero-term shadow rays
     for (uint32_t b = 0; b < d.max_depth; b++) {
         // live state of bounce b sits in view b & 1 (k_raygen wrote view 0), k_shade moves the survivors to the other one
@@ -1206,7 +1239,7 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
             if (tm) { int e = tm->begin(FAM_MIXED); if (e) return e; }
             if (fast) hipLaunchKernelGGL((k_trace32<kTraceMixed>), dim3(g_trace32), dim3(kBlock), 0, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, 0u,
                                          (const uint32_t*)q_next, (const unsigned int*)n_next, ctr, &ctr->trace_head, c->refill_min, 0u);
-            else launch_mixed(s->use_rest, shp, g_trace, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, (const uint32_t*)q_next,
+            else launch_mixed(s->use_rest, shp, c->tail_res != nullptr, g_trace, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, (const uint32_t*)q_next,
                               (const unsigned int*)n_next, ctr, &ctr->trace_head,
                               (s->use_rest ? c->refill_min_hyb | (c->refill_min_any_hyb << 16) : c->refill_min | (c->refill_min_any << 16)) | (c->steal ? 0x8000u : 0u) | shp_bit);
             if (tm) { int e = tm->end(); if (e) return e; }
@@ -1410,6 +1443,7 @@ int render_local(cray_ctx* c, cray_scene* s, const cray_render_params* prm, cray
     if ((e = choose_trace_records(c, s, prm->count_traversal != 0 || prm->precision != CRAY_PRECISION_F64,
                                   n_pix_rank * (size_t)(s_end > s_begin ? s_end - s_begin : 0), &measuring))) return e;
     const uint32_t used_records = (uint32_t)(s->use_b0 | (s->use_rest << 4));   // what THIS call's launches read (cray_stats.trace_records)
+    if ((e = ensure_tail(c, s))) return e;
     if ((e = ensure_tile_order(c, s, *prm, n_pix_rank * (size_t)(s_end > s_begin ? s_end - s_begin : 0)))) return e;
     const size_t film_floats = (size_t)W * H * 3;
     if ((e = ensure_buffer(&c->film, &c->film_floats, film_floats))) return e;
@@ -1601,6 +1635,7 @@ extern "C" int cray_trace(cray_ctx* c, cray_scene* s, const cray_ray* rays, size
     }
     for (size_t i = 0; i < n; i++) col[i] = rays[i].tmax;
     HIP_TRY(hipMemcpy(ps.stmax, col.data(), n * 8, hipMemcpyHostToDevice));
+    if ((e = ensure_tail(c, s))) return e;   // (before the counters are reset: they carry the small-launch threshold and table)
     if ((e = reset_counters(c))) return e;
     // any-hit resolution adds `contribution` to L: use L as the "unoccluded" flag (0 + 1)
     if (do_any) {
@@ -1632,8 +1667,8 @@ extern "C" int cray_trace(cray_ctx* c, cray_scene* s, const cray_ray* rays, size
         HIP_TRY(hipMemcpy(c->shadow_queue, iota.data(), n * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(&ctr->n_shadow, &cnt, sizeof(cnt), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(&ctr->n_active0, &cnt, sizeof(cnt), hipMemcpyHostToDevice));
-        launch_mixed(level, shp, g, c->stream, s->dev, ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, (const uint32_t*)nullptr,
-                     (const unsigned int*)&ctr->n_active0, ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16) | (c->steal ? 0x8000u : 0u) | (shp ? 0x4000u : 0u));
+        launch_mixed(level, shp, c->tail_res != nullptr, g, c->stream, s->dev, ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, (const uint32_t*)nullptr,
+                     (const unsigned int*)&ctr->n_active0, ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16) | (c->steal ? 0x8000u : 0u) | (shp ? 0x4000u : 0u) | (c->tail_seg ? 0x2000u : 0u));
     } else {
 #define CRAY_TRACE_GO(ANY_, COUNT_, TMAX_)                                                                                       \
     launch_trace<ANY_, COUNT_>(level, shp, g, c->stream, s->dev, ps, (const uint32_t*)nullptr, (const unsigned int*)nullptr, (uint32_t)n, TMAX_, ctr, \

@@ -63,7 +63,21 @@ constexpr uint32_t kTraceLdsShapes = 8;   // sphere + disk records (272 B each) 
 //               enclosure cannot certify is retaken from the f64 record in a RESOLVE step of the lane.  Same hits, same counters.
 //  HYB = 2    : the same with pair lines (InnerNodeP): the record of the child a lane descends into may already be in its registers.
 //  SHAPES_LDS : the scene's few sphere / disk records are staged in LDS by every block (the host picks this instantiation when they fit).
-template <int MODE, bool COUNT, int HYB, bool SHAPES_LDS = false>
+//  TAIL       : the instantiation for SMALL mixed launches (fewer than Counters::tail_rays rays): such a launch is all drain — every
+//               lane holds one or two rays from the start and the launch lasts as long as its longest ray — so here idle lanes
+//               take over parts of unfinished rays of both kinds.  Shadow rays as in the any-hit launch (STEAL).  A CLOSEST-hit ray
+//               hands the bottom entry of its stack to a helper, which walks that subtree with the ray's tmax of that moment —
+//               never below the tmax the reference has when it gets there, so the helper enters a superset of the reference's
+//               nodes and accepts a superset of its hits.  Its best hit is the reference's answer for the subtree if every box on
+//               the path from the stolen node to the hit's leaf has a key below the hit distance (then the reference, whatever
+//               its tmax, enters them all): the helper tracks "keys non-decreasing along my path" (one bit per deferred child)
+//               and certifies a hit when that holds and the leaf's box key is below the hit.  The ray's own lane walks the
+//               reference's order with the reference's tmax (what it gave away comes LAST in that order), then folds the helpers'
+//               results in traversal order — latest helper first, a tie keeps the earlier hit, as the reference's strict `<` does.
+//               A helper's hit that would win without being certified — the reference's leak cases — makes the lane walk the
+//               whole ray again alone.  Helpers do not hand work on.
+enum : uint32_t { kTfThief = 1u, kTfMono = 2u, kTfCert = 4u, kTfWait = 8u, kTfNoDonate = 16u };   // + bits 8..10 helpers so far, 12..13 this helper's slot
+template <int MODE, bool COUNT, int HYB, bool SHAPES_LDS = false, bool TAIL = false>
 __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& ps, const uint32_t* __restrict__ queue, const uint32_t n_first,
                                            const uint32_t* __restrict__ queue_b, const uint32_t n_b, const double* __restrict__ closest_tmax,
                                            Counters* ctr, unsigned int* work_head, unsigned int refill_min) {
@@ -84,8 +98,15 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
     // Built into the any-hit launch only (the last bounce of a pass): inside the loop of the mixed launches the same code cost
     // 9 % of the bulk (two spilled registers, compares in every iteration) for -0.2 ms of tail per launch — their tails are
     // mostly closest-hit rays once a launch is small (profiles/r04_experiments.md).
-    constexpr bool STEAL = !COUNT && !HYB && MODE == kTraceAny;
+    static_assert(!TAIL || (MODE == kTraceMixed && !COUNT && HYB == 0), "the small-launch instantiation reads f64 records");
+    constexpr bool STEAL = !COUNT && !HYB && (MODE == kTraceAny || TAIL);
     const bool steal_on = STEAL && (refill_min & 0x8000u) != 0;
+    unsigned int age = 0, age_min = 0;   // TAIL: iterations this lane's segment has been walked / before it may hand parts out
+    if (MODE == kTraceMixed && !COUNT) {   // a mixed launch runs in one of two instantiations, by its size (both are launched)
+        const unsigned int tr = ctr->tail_rays & 0xffffffu;
+        age_min = (ctr->tail_rays >> 24) * 4u;
+        if (TAIL ? (tr == 0u || n_first + n_b >= tr) : (tr != 0u && n_first + n_b < tr)) return;
+    }
     const uint32_t n = n_first + n_b;
     bool is_any = MODE == kTraceAny;          // per lane in mixed mode
 #define CRAY_ANY_LANE (MODE == kTraceMixed ? is_any : (MODE == kTraceAny))
@@ -133,6 +154,9 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
     int sbase = 0;              // bottom of this lane's stack: entries [sbase, sp) are its own, [0, sbase) were given away
     uint32_t owner = tid;       // thread whose grp_cnt / grp_occ entry this lane's ray uses
     bool shared = false;        // this lane's ray has (had) other workers
+    double kcur = 0.0;          // TAIL, helper of a closest-hit ray: the key of the node `cur`
+    uint32_t tfl = 0;           // TAIL: kTf* flags of this lane
+    unsigned int n_help = 0, n_again = 0;   // TAIL: parts of segments this lane handed to helpers / rays it walked again (cray_stats.tail_split)
     // (r_: reference, w0_ / w1_: the two payload words)
 #define CRAY_PUSH_W(r_, w0_, w1_)                                                          \
     do {                                                                                   \
@@ -222,6 +246,10 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
         if (n_tri) atomicAdd(ANY ? &ctr->shadow_tri : &ctr->closest_tri, n_tri);
     }
     if (overflow) atomicAdd(&ctr->stack_overflow, 1ull);
+    if (TAIL) {
+        if (n_help) atomicAdd(&ctr->tail_helped, (unsigned long long)n_help);
+        if (n_again) atomicAdd(&ctr->tail_again, (unsigned long long)n_again);
+    }
 #ifdef CRAY_TRACE_DIAG
     if (lane == 0)
         for (int k = 0; k < 16; k++) atomicAdd(&ctr->diag[(ANY ? 16 : 0) + k], dg[k]);
@@ -241,12 +269,12 @@ __global__ void CRAY_TRACE_EU __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trac
 }
 
 // shadow rays of one bounce (any_queue) + path segments of the next (closest_queue) in one persistent launch
-template <int HYB, bool SHAPES_LDS = false>
+template <int HYB, bool SHAPES_LDS = false, bool TAIL = false>
 __global__ void CRAY_TRACE_EU __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace_mixed(DevScene sc, PathState ps, const uint32_t* __restrict__ any_queue,
                                                   const unsigned int* __restrict__ n_any_ptr, const uint32_t* __restrict__ closest_queue,
                                                   const unsigned int* __restrict__ n_closest_ptr, Counters* ctr, unsigned int* work_head,
                                                   unsigned int refill_min) {
-    trace_body<kTraceMixed, false, HYB, SHAPES_LDS>(sc, ps, any_queue, *n_any_ptr, closest_queue, *n_closest_ptr, nullptr, ctr, work_head, refill_min);
+    trace_body<kTraceMixed, false, HYB, SHAPES_LDS, TAIL>(sc, ps, any_queue, *n_any_ptr, closest_queue, *n_closest_ptr, nullptr, ctr, work_head, refill_min);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -153,7 +153,10 @@ typedef struct {
                                                scene whichever its first two frames show to be faster */
     double trace_mixed_ms;                  /* launches that trace the shadow rays of bounce b together with the
                                                path segments of bounce b+1 (not used with count_traversal) */
-    uint32_t trace_mixed_launches, pad2_;
+    uint32_t trace_mixed_launches;
+    uint32_t tail_split;                    /* small launches: low 24 bits = parts of closest-hit rays that idle lanes
+                                               walked as helpers (saturating); high 8 bits = rays walked again alone because a helper's
+                                               winning hit could not be certified (saturating) */
     uint64_t closest_hits;                  /* of closest_rays: segments that hit a primitive (the paths k_shade shades fully) */
 } cray_stats;
 

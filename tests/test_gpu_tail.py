@@ -1,0 +1,86 @@
+"""Small mixed launches run in the instantiation that lets idle lanes walk parts of unfinished rays of BOTH kinds (trace_body TAIL,
+DESIGN.md 3.1).  For a closest-hit ray that is only the reference's traversal if the helpers' results are folded in traversal
+order and a helper's winning hit is certified (every box on its path has a key below the hit) — otherwise the ray is walked
+again alone.  Films, per-ray records and ray counts must be the oracle's with the instantiation on (default) and off
+(CRAY_TAIL_RAYS=0), on scenes whose launches are all small, including the scene built around the reference's leak
+(scenes/rounding-error.cry: origins a hair outside a box) and rays that start exactly on box planes.
+Seam: Bvh::intersect, src/bvh.rs:58-104; Bounds::intersects, src/bounds.rs:62-88."""
+import os
+
+import numpy as np
+import pytest
+
+from craytracer_amd import backend, scenes
+from oracle import oracle_lib as ol
+from tests.parity_util import small_scenes, random_rays
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(tail_rays):
+    old = os.environ.get('CRAY_TAIL_RAYS')
+    os.environ['CRAY_TAIL_RAYS'] = tail_rays
+    try:
+        return backend.Context(0)
+    finally:
+        if old is None:
+            del os.environ['CRAY_TAIL_RAYS']
+        else:
+            os.environ['CRAY_TAIL_RAYS'] = old
+
+
+@pytest.fixture(scope='module')
+def ctxs():
+    on, off = _ctx(str(2 << 20)), _ctx('0')
+    yield on, off
+    on.close(); off.close()
+
+
+@pytest.mark.parametrize('name', [n for n, _ in small_scenes()])
+def test_small_launches_with_helpers_give_the_reference_film(ctxs, name):
+    on, off = ctxs
+    sc = dict(small_scenes())[name]
+    ref, ost = ol.OracleScene(sc).render(seed=11)
+    host = backend.HostScene(sc)
+    don, doff = on.upload(host), off.upload(host)
+    f1, s1 = don.render(seed=11)
+    f0, s0 = doff.render(seed=11)
+    assert np.array_equal(f1, ref) and np.array_equal(f0, ref)
+    assert s1['closest_rays'] == ost['closest_rays'] and s1['shadow_rays'] == ost['shadow_rays']
+    assert s0['tail_split'] == 0
+    don.close(); doff.close()
+
+
+def test_helpers_are_really_used_and_per_ray_records_are_the_reference_s(ctxs):
+    """A mesh deep enough for long rays, few enough rays for every launch to be small: helpers must have walked parts of
+    closest-hit rays (cray_stats.tail_split), and the mixed launch's per-ray answers must be the oracle's — also for rays that
+    start exactly on bounding planes of nodes, where the reference's slab test is at its most fragile."""
+    on, _ = ctxs
+    sc = scenes.dragon(160, 96, 4, 6, nu=200, nv=500)
+    dev = on.upload(backend.HostScene(sc))
+    orc = ol.OracleScene(sc)
+    f, st = dev.render(seed=3)
+    ref, _ = orc.render(seed=3)
+    assert np.array_equal(f, ref)
+    assert (st['tail_split'] & 0xffffff) > 0, 'no part of a closest-hit ray was walked by a helper'
+    rays = random_rays(orc, 6000, seed=5)
+    nodes, _ = orc.bvh()
+    rng = np.random.default_rng(9)
+    pick = nodes[rng.integers(0, len(nodes), 3000)]
+    pts = np.where(rng.random((3000, 3)) < 0.5, pick['bmin'], pick['bmax'])
+    pts = pts[np.all(np.abs(pts) < 1e6, axis=1)]
+    extra = np.zeros((len(pts), 7))
+    extra[:, :3] = pts
+    d = rng.normal(size=(len(pts), 3))
+    d[rng.random(len(pts)) < 0.3, 0] = 0.0
+    extra[:, 3:6] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    extra[:, 6] = np.inf
+    rays = np.concatenate([rays, extra])
+    o, _ = orc.trace(rays)
+    oa, _ = orc.trace(rays, any_hit=True)
+    got_any, got_closest = dev.trace_mixed(rays)
+    assert np.array_equal(got_any['hit'], oa['hit'])
+    assert np.array_equal(got_closest['hit'], o['hit'])
+    h = o['hit'] != 0
+    assert np.array_equal(got_closest['prim'][h], o['prim'][h]) and np.array_equal(got_closest['t'][h], o['t'][h])
+    dev.close()

@@ -17,7 +17,7 @@ export TMPDIR=/tmp
 # The library times a scene's first two frames to choose the records its traversal launches read (f64 or certified f32 culling, per
 # launch kind): a plain bench run first says what it chose; every profiled pass below is PINNED to that choice, so that the one frame
 # of a counter pass and the timed frames of the stats pass run the steady-state kernels and nothing else.
-python3 bench.py --workload $wl --steps 2 --warmup 2 --cpu-baseline 0 --count-pass 0 > $out/choice.log 2> /dev/null
+python3 bench.py --workload $wl --steps 2 --warmup 2 --cpu-baseline 0 --count-pass 0 > $out/choice.log 2> $out/choice.err
 pin=$(python3 - "$out/choice.log" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read())

@@ -51,7 +51,9 @@ def main():
             dt, st = best
             per_rank.append({'rank': rank, 'ms': round(dt * 1e3, 2), 'rays': st['closest_rays'] + st['shadow_rays'] - st['shadow_skipped'],
                              'closest_ms': round(st['trace_closest_ms'], 2), 'mixed_ms': round(st['trace_mixed_ms'], 2), 'any_ms': round(st['trace_any_ms'], 2),
-                             'shade_ms': round(st['shade_ms'], 2), 'other_ms': round(st['other_ms'], 2)})
+                             'shade_ms': round(st['shade_ms'], 2), 'other_ms': round(st['other_ms'], 2), 'tail_split': [st.get('tail_split', 0) & 0xffffff, st.get('tail_split', 0) >> 24]})
+        if not per_rank:
+            continue
         worst = max(r['ms'] for r in per_rank)
         if base is None:
             base = worst
