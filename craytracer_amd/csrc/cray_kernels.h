@@ -74,8 +74,9 @@ constexpr uint32_t kTraceLdsShapes = 8;   // sphere + disk records (272 B each) 
 //               and certifies a hit when that holds and the leaf's box key is below the hit.  The ray's own lane walks the
 //               reference's order with the reference's tmax (what it gave away comes LAST in that order), then folds the helpers'
 //               results in traversal order — latest helper first, a tie keeps the earlier hit, as the reference's strict `<` does.
-//               A helper's hit that would win without being certified — the reference's leak cases — makes the lane walk the
-//               whole ray again alone.  Helpers do not hand work on.
+//               A helper's hit that would win without being certified — the reference's leak cases — makes the lane walk THAT
+//               part again itself, at its place in the order and with the tmax the fold has reached: the reference's own walk
+//               of it.  Helpers do not hand work on.
 enum : uint32_t { kTfThief = 1u, kTfMono = 2u, kTfCert = 4u, kTfWait = 8u, kTfNoDonate = 16u };   // + bits 8..10 helpers so far, 12..13 this helper's slot
 template <int MODE, bool COUNT, int HYB, bool SHAPES_LDS = false, bool TAIL = false>
 __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& ps, const uint32_t* __restrict__ queue, const uint32_t n_first,
