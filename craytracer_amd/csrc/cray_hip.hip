@@ -11,6 +11,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -102,7 +103,7 @@ struct cray_ctx {
     uint32_t* pix_render = nullptr;
     size_t pix_render_capacity = 0;
     const uint32_t* pix_order = nullptr;          // what run_pass reads: pix_render or pix_list
-    const void* order_scene = nullptr;            // the scene and pixel list pix_render was computed for
+    uint64_t order_scene = 0;                     // uid of the scene, and the pixel list, pix_render was computed for
     uint64_t order_key[6] = {0, 0, 0, 0, 0, 0};
     bool order_valid = false;
     int tile_order = 1;                           // CRAY_TILE_ORDER=0: render in the canonical tile order
@@ -130,7 +131,9 @@ struct cray_ctx {
     std::vector<size_t> rank_offset;     // world + 1 prefix sums of the per-rank pixel counts
 };
 
+static std::atomic<uint64_t> g_scene_uid{1};
 struct cray_scene {
+    uint64_t uid = g_scene_uid.fetch_add(1);   // never reused (a freed scene's address may be): what per-scene caches of a ctx are keyed on
     cray_ctx* ctx = nullptr;
     DevScene dev{};
     std::vector<void*> allocs;
@@ -1377,7 +1380,7 @@ int ensure_tile_order(cray_ctx* c, cray_scene* s, const cray_render_params& prm,
     c->pix_order = c->pix_list;
     const uint32_t W = s->dev.film_w, H = s->dev.film_h;
     if (!c->tile_order || n_paths < ((size_t)1 << 21) || s->dev.n_inner == 0) return CRAY_OK;
-    if (c->order_valid && c->order_scene == (const void*)s && memcmp(c->order_key, c->pix_key, sizeof(c->order_key)) == 0) { c->pix_order = c->pix_render; return CRAY_OK; }
+    if (c->order_valid && c->order_scene == s->uid && memcmp(c->order_key, c->pix_key, sizeof(c->order_key)) == 0) { c->pix_order = c->pix_render; return CRAY_OK; }
     c->order_valid = false;
     try {
         // the rank's tiles, as rank_pixels walks them
@@ -1419,7 +1422,7 @@ int ensure_tile_order(cray_ctx* c, cray_scene* s, const cray_render_params& prm,
         HIP_TRY(hipMemcpyAsync(c->pix_render, out.data(), out.size() * 4, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));   // `out` is a local vector
     } catch (const std::exception& ex) { set_last_error("tile order: %s", ex.what()); return CRAY_ERR_INVALID; }
-    c->order_scene = (const void*)s;
+    c->order_scene = s->uid;
     memcpy(c->order_key, c->pix_key, sizeof(c->order_key));
     c->order_valid = true;
     c->pix_order = c->pix_render;

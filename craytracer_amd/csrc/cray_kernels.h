@@ -98,7 +98,8 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
     // Not used by the counting builds (the reference's early exit defines their counters) nor with HYB.
     // Built into the any-hit launch only (the last bounce of a pass): inside the loop of the mixed launches the same code cost
     // 9 % of the bulk (two spilled registers, compares in every iteration) for -0.2 ms of tail per launch — their tails are
-    // mostly closest-hit rays once a launch is small (profiles/r04_experiments.md).
+    // mostly closest-hit rays once a launch is small (profiles/r04_experiments.md).  The opt-in small-launch instantiation
+    // (TAIL, below) has it as well, together with the certified split of closest-hit rays.
     static_assert(!TAIL || (MODE == kTraceMixed && !COUNT && HYB == 0), "the small-launch instantiation reads f64 records");
     constexpr bool STEAL = !COUNT && !HYB && (MODE == kTraceAny || TAIL);
     const bool steal_on = STEAL && (refill_min & 0x8000u) != 0;
