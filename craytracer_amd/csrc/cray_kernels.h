@@ -187,10 +187,15 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
     bool pending = false;  // ray finished, result still in registers (written at the next refill)
     unsigned int res_base = 0, res_left = 0;  // wave-uniform reserve of queue positions
 #ifndef CRAY_CHUNK_MAX
-#define CRAY_CHUNK_MAX 256u   // 128 / 256 / 512 / 1024 / 2048 measured: 256 is best by ~0.5 % (bounce 0: -3.5 %), 1024 and up cost 2-6 %
+#define CRAY_CHUNK_MAX 512u   // round 3 (f64 records): 256 best by ~0.5 %.  Round 4 (f32 culling; whole frame, bounce 0 / mixed): 128: 29.0 /
+                              // 127.3 ms, 256: 26.5 / 126.7, 512: 25.95 / 126.6, 1024: 26.1 / 127.8, 2048: 26.5 / 130.3, 4096: 27.6 / 135.2.  But what
+                              // a wave holds in reserve is what a SMALL launch waits for (an eighth of the frame, bounce 0: 3.8 ms at 256, 7.0 at
+                              // 1024), hence at least 16 chunks per wave below, not 4 (profiles/r04_chunk_size_ab.log)
 #endif
-    unsigned int chunk = n / (gridDim.x * (kBlock / 64) * 4u);
-    chunk = chunk < 64u ? 64u : (chunk > CRAY_CHUNK_MAX ? CRAY_CHUNK_MAX : chunk);
+    // (the f64 instantiations keep round 3's rule — at least four chunks per wave, at most 256 positions: with the new one
+    // configs[1]'s mixed launches were 2.5 % slower, 7.97 -> 8.17 ms)
+    unsigned int chunk = n / (gridDim.x * (kBlock / 64) * (HYB ? 16u : 4u));
+    chunk = chunk < 64u ? 64u : (chunk > (HYB ? CRAY_CHUNK_MAX : 256u) ? (HYB ? CRAY_CHUNK_MAX : 256u) : chunk);
     uint32_t p = 0, cur = 0;
     ray_t ray = mkray(mk(0, 0, 0), mk(0, 0, 1));
     vec3 rd = mk(0, 0, 1);   // 1 / ray.d per axis (exact-division helper)
