@@ -49,8 +49,12 @@ def test_pack_and_unpack_follow_rank_pixels(ctx, w, h, tile, world):
 def test_world1_communicator_runs_through_rccl():
     c = backend.Context(0)
     assert c.comm_rank() == 0 and c.comm_world_size() == 1
+    info = c.comm_describe()                                        # no communicator yet: one rank, nothing loaded
+    assert (info['world'], info['rank'], info['ranks_seen'], info['transport']) == (1, 0, 1, 'none')
     c.comm_init(backend.Context.comm_unique_id(), 0, 1)
     assert c.comm_rank() == 0 and c.comm_world_size() == 1
+    info = c.comm_describe()                                        # the real collective library, counted by its own all-reduce
+    assert info['world'] == 1 and info['ranks_seen'] == 1 and info['transport'] == 'rccl' and info['rccl_version'] > 0, info
     c.barrier()
     assert np.array_equal(c.allreduce([1.5, -2.0, 7.0], 'sum'), [1.5, -2.0, 7.0])
     assert np.array_equal(c.allreduce([3.0], 'max'), [3.0])
