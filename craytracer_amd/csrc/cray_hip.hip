@@ -64,6 +64,7 @@ struct cray_ctx {
     // more): 20 / 20 is 1 % faster than 28 / 28 on configs[2]; the f64 launches of configs[3] lose 2 % at 20 / 20
     // (profiles/r04_refill_sweep_f32_culling*.log)
     unsigned int refill_min_hyb = 20, refill_min_any_hyb = 20;
+    unsigned int leaf_min = 10;    // lanes of a wave that must be at a leaf slot before the leaf step runs (mixed / any-hit launches; 0 or 1: no waiting)
     unsigned int lds_shapes = 1;   // the few sphere / disk records of a scene staged in LDS by the traversal launches (CRAY_LDS_SHAPES=0: read global memory)
     unsigned int steal = 1;   // work sharing among the lanes of a wave in the drain of the shadow-ray launches (trace_body, STEAL); CRAY_STEAL=0 turns it off
     int trace_blocks_per_cu = 4;
@@ -394,6 +395,7 @@ extern "C" int cray_ctx_create(int device_id, void* stream, cray_ctx** out) {
     c->steal = (unsigned int)env_int("CRAY_STEAL", 0, 1, (int)c->steal);
     c->lds_shapes = (unsigned int)env_int("CRAY_LDS_SHAPES", 0, 1, (int)c->lds_shapes);
     c->tile_order = env_int("CRAY_TILE_ORDER", 0, 1, c->tile_order);
+    c->leaf_min = (unsigned int)env_int("CRAY_LEAF_MIN", 0, 63, (int)c->leaf_min);
     c->tail_rays = (unsigned int)env_int("CRAY_TAIL_RAYS", 0, (1 << 24) - 1, (int)c->tail_rays);
     c->tail_seg = (unsigned int)env_int("CRAY_TAIL_SEG", 0, 1, (int)c->tail_seg);
     c->tail_age = (unsigned int)env_int("CRAY_TAIL_AGE", 0, 255, (int)c->tail_age);
@@ -1244,7 +1246,7 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
                                          (const uint32_t*)q_next, (const unsigned int*)n_next, ctr, &ctr->trace_head, c->refill_min, 0u);
             else launch_mixed(s->use_rest, shp, c->tail_res != nullptr, g_trace, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, (const uint32_t*)q_next,
                               (const unsigned int*)n_next, ctr, &ctr->trace_head,
-                              (s->use_rest ? c->refill_min_hyb | (c->refill_min_any_hyb << 16) : c->refill_min | (c->refill_min_any << 16)) | (c->steal ? 0x8000u : 0u) | shp_bit);
+                              (s->use_rest ? c->refill_min_hyb | (c->refill_min_any_hyb << 16) : c->refill_min | (c->refill_min_any << 16)) | (c->leaf_min << 7) | (c->steal ? 0x8000u : 0u) | shp_bit);
             if (tm) { int e = tm->end(); if (e) return e; }
         } else {
             if (tm) { int e = tm->begin(FAM_ANY); if (e) return e; }
