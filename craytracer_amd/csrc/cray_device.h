@@ -72,7 +72,7 @@ struct alignas(16) LeafSlot32 {
 };
 static_assert(sizeof(LeafSlot32) == 48, "LeafSlot32 is three 16-B loads");
 
-// ---- certified f32 culling of the exact traversal (cray_math.h hyb_node): the two children's bounds, rounded outward to f32
+// ---- certified f32 culling of the exact traversal (cray_math.h hyb_pair): the two children's bounds, rounded outward to f32
 // and INTERLEAVED by child — (lo[axis][child], hi[axis][child]) — so that a 64-bit register pair holds one coordinate of both
 // boxes and the slab arithmetic of the pair is packed f32 math.
 struct alignas(64) InnerNodeH {

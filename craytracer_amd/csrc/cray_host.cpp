@@ -658,7 +658,7 @@ extern "C" uint64_t cray_host_hyb_key_violations(const double* lo, const double*
                                                  uint64_t n, uint64_t* counts /* [4]: resolve, visit, cull, out-of-range rays */) {
     using namespace cray;
     uint64_t bad = 0, cnt[4] = {0, 0, 0, 0};
-    // boxes i and i + 1 are the two children of one node, tested by the ray and tmax of sample i through hyb_node (what the
+    // boxes i and i + 1 are the two children of one node, tested by the ray and tmax of sample i through hyb_pair (what the
     // kernel runs at a node); box i again alone through hyb_key + hyb_status (what it runs at a pop)
     for (uint64_t i = 0; i + 1 < n; i++) {
         const double *oo = o + 3 * i, *dd = d + 3 * i;
@@ -679,25 +679,34 @@ extern "C" uint64_t cray_host_hyb_key_violations(const double* lo, const double*
         hyb_f2 l32[3], h32[3];
         for (int k = 0; k < 3; k++)
             for (int c = 0; c < 2; c++) { l32[k][c] = f32_down(lo[3 * (i + c) + k]); h32[k][c] = f32_up(hi[3 * (i + c) + k]); }
-        const HybNode hn = hyb_node(l32[0], l32[1], l32[2], h32[0], h32[1], h32[2], hr.ox, hr.oy, hr.oz, hr.rx, hr.ry, hr.rz, hr.a, t_lo, t_hi);
+        // hyb_pair once per order of the two children: the near child's decision and the far child's decision + key estimate
+        int st_[2][2]; float kc_[2] = {0.f, 0.f};   // st_[c][0]: child c as the near one, [1]: as the far one
+        for (int rf = 0; rf < 2; rf++) {
+            const HybPair hp = hyb_pair(l32[0], l32[1], l32[2], h32[0], h32[1], h32[2], hr.px, hr.py, hr.pz, hr.rx, hr.ry, hr.rz, hr.a, t_lo, t_hi, rf != 0);
+            const int cn = rf, cf = 1 - rf;
+            st_[cn][0] = hp.cull_n ? kHybCull : (hp.visit_n ? kHybVisit : kHybResolve);
+            st_[cf][1] = hp.cull_f ? kHybCull : (hp.visit_f ? kHybVisit : kHybResolve);
+            kc_[cf] = hp.kc_f;
+        }
         for (int c = 0; c < 2; c++) {
             const double key = child_key(lo + 3 * (i + c), hi + 3 * (i + c), ov, dv);   // the literal restatement of the reference
             const bool accept = key < tmax[i];
-            const int st = hn.s[c];
+            if (st_[c][0] != st_[c][1]) bad++;   // a child is classified the same way wherever it stands in the order
+            const int st = st_[c][0];
             if (c == 0) cnt[st]++;
             if ((st == kHybVisit && !accept) || (st == kHybCull && accept)) bad++;
             // the deferred form: the encoded key against another (smaller) tmax, as at a pop
             const double tm2 = c == 0 ? tmax[i] : tmax[i] * 0.5;
             float a_lo, a_hi;
             hyb_tmax(tm2, a_lo, a_hi);
-            const int st2 = hyb_status(hn.kc[c], hr.a, a_lo, a_hi);
+            const int st2 = hyb_status(kc_[c], hr.a, a_lo, a_hi);
             const bool accept2 = key < tm2;
             if ((st2 == kHybVisit && !accept2) || (st2 == kHybCull && accept2)) bad++;
         }
         // the single-box classifier must encode the same key
         float l1[3] = {l32[0][0], l32[1][0], l32[2][0]}, h1[3] = {h32[0][0], h32[1][0], h32[2][0]};
         const float kc1 = hyb_key(l1, h1, hr);
-        if (memcmp(&kc1, &hn.kc[0], 4) != 0 && !(kc1 != kc1 && hn.kc[0] != hn.kc[0])) bad++;
+        if (memcmp(&kc1, &kc_[0], 4) != 0 && !(kc1 != kc1 && kc_[0] != kc_[0])) bad++;
     }
     if (counts) for (int k = 0; k < 4; k++) counts[k] = cnt[k];
     return bad;

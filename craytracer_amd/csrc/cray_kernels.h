@@ -205,7 +205,7 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
     int32_t hit_prim = -1;
     // HYB: the f32 view of the ray, [t_lo, t_hi] around ray.tmax, and the RESOLVE state: `cur` was reached on an uncertified
     // decision, `res` = parent | side << 31 names the f64 bounds that decide it
-    float h_ox = 0.f, h_oy = 0.f, h_oz = 0.f, h_rx = 1.f, h_ry = 1.f, h_rz = 1.f, h_a = 0.f;   // HybRay, kept as scalars (an aggregate in the
+    float h_px = 0.f, h_py = 0.f, h_pz = 0.f, h_rx = 1.f, h_ry = 1.f, h_rz = 1.f, h_a = 0.f;   // HybRay, kept as scalars (an aggregate in the
                                                                                               // lane state ends up partly in LDS)
     float t_lo = 0.f, t_hi = 0.f;
     uint32_t res = 0;

@@ -310,7 +310,7 @@ CRAY_HD float f32_up(double x) {
 #endif
 }
 struct HybRay {   // (scalars, not arrays: a struct of arrays in a kernel's lane state gets promoted to LDS by the compiler)
-    float ox, oy, oz, rx, ry, rz;
+    float px, py, pz, rx, ry, rz;   // o / d and 1 / d per axis, each rounded once from f64: a slab quotient is fma(bound, r, -p)
     float a;   // NaN: this ray is outside the certified range, every decision is resolved exactly
 };
 constexpr float kHybC = 0x1p-21f;     // 8u
@@ -324,7 +324,7 @@ CRAY_HD bool hyb_scene_ok(const double* root_lo, const double* root_hi) {  // ev
 }
 CRAY_HD HybRay hyb_ray(vec3 o, vec3 d, vec3 rd, bool fast_div) {
     HybRay h;
-    h.ox = (float)o.x; h.oy = (float)o.y; h.oz = (float)o.z;
+    h.px = (float)(o.x * rd.x); h.py = (float)(o.y * rd.y); h.pz = (float)(o.z * rd.z);
     h.rx = (float)rd.x; h.ry = (float)rd.y; h.rz = (float)rd.z;
     const double ax = fabs(d.x), ay = fabs(d.y), az = fabs(d.z);
     const bool ok = fast_div && ax >= 0x1p-30 && ax <= 0x1p30 && ay >= 0x1p-30 && ay <= 0x1p30 && az >= 0x1p-30 && az <= 0x1p30 &&
@@ -342,9 +342,9 @@ CRAY_HD void hyb_tmax(double t, float& t_lo, float& t_hi) {
     t_hi = ok ? x * (1.0f + 0x1p-22f) : __builtin_huge_valf();
 }
 CRAY_HD float hyb_key(const float* lo, const float* hi, const HybRay& h) {
-    const float ax = (lo[0] - h.ox) * h.rx, bx = (hi[0] - h.ox) * h.rx;
-    const float ay = (lo[1] - h.oy) * h.ry, by = (hi[1] - h.oy) * h.ry;
-    const float az = (lo[2] - h.oz) * h.rz, bz = (hi[2] - h.oz) * h.rz;
+    const float ax = fmaf(lo[0], h.rx, -h.px), bx = fmaf(hi[0], h.rx, -h.px);
+    const float ay = fmaf(lo[1], h.ry, -h.py), by = fmaf(hi[1], h.ry, -h.py);
+    const float az = fmaf(lo[2], h.rz, -h.pz), bz = fmaf(hi[2], h.rz, -h.pz);
     const float tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
     const float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
     const float e0 = fmaf(kHybC, fabsf(tmin), h.a), e1 = fmaf(kHybC, fabsf(tmax), h.a);
@@ -363,27 +363,45 @@ CRAY_HD int hyb_status(float kc, float a, float t_lo, float t_hi) {   // a poppe
 }
 
 // Both children of a node at once, as the kernel evaluates them: the record holds the two children's bounds interleaved
-// (InnerNodeH: lo[axis][child], hi[axis][child]), so the slab arithmetic runs on float2 = one packed instruction (v_pk_add_f32,
-// v_pk_mul_f32, v_pk_fma_f32) for both boxes.  Same classification as hyb_key + hyb_status, fused: the enclosure ends are the
-// very values hyb_status would recompute from kc.
+// (InnerNodeH: lo[axis][child], hi[axis][child]), so the slab arithmetic is one packed instruction (v_pk_fma_f32) per bound for
+// both boxes.  Same classification as hyb_key + hyb_status, fused: the enclosure ends are the very values hyb_status would
+// recompute from kc.  The children are put in the ray's order (bvh.rs:92-98) BEFORE they are classified, so the step gets what
+// it branches on — may the near child be entered, is it certain; the same for the far child and the key estimate it is deferred
+// with — as conditions, not as codes to select and compare again, and the near child's key estimate is never formed.
 typedef float hyb_f2 __attribute__((ext_vector_type(2)));
-struct HybNode {
-    int s[2];      // kHybVisit / kHybCull / kHybResolve of child 0 / 1 against [t_lo, t_hi]
-    float kc[2];   // encoded key estimates (what a deferred child carries on the stack)
+struct HybPair {
+    bool visit_n, cull_n;   // near child: key < tmax certainly / key >= tmax certainly (neither: RESOLVE)
+    bool visit_f, cull_f;   // far child
+    float kc_f;             // the far child's encoded key estimate (what it carries on the stack)
 };
+CRAY_HD hyb_f2 hyb_slab(hyb_f2 b, float r, float p) {
+#ifdef __HIP_DEVICE_COMPILE__
+    return __builtin_elementwise_fma(b, hyb_f2{r, r}, hyb_f2{-p, -p});
+#else
+    return hyb_f2{fmaf(b[0], r, -p), fmaf(b[1], r, -p)};
+#endif
+}
 // (the ray's f32 view as seven scalars: the kernel keeps them in registers, an aggregate argument makes the compiler build it in LDS)
-CRAY_HD HybNode hyb_node(hyb_f2 lox, hyb_f2 loy, hyb_f2 loz, hyb_f2 hix, hyb_f2 hiy, hyb_f2 hiz, float h_ox, float h_oy, float h_oz,
-                         float h_rx, float h_ry, float h_rz, float h_a, float t_lo, float t_hi) {
-    const hyb_f2 ax = (lox - h_ox) * h_rx, bx = (hix - h_ox) * h_rx;
-    const hyb_f2 ay = (loy - h_oy) * h_ry, by = (hiy - h_oy) * h_ry;
-    const hyb_f2 az = (loz - h_oz) * h_rz, bz = (hiz - h_oz) * h_rz;
-    HybNode out;
+CRAY_HD HybPair hyb_pair(hyb_f2 lox, hyb_f2 loy, hyb_f2 loz, hyb_f2 hix, hyb_f2 hiy, hyb_f2 hiz, float h_px, float h_py, float h_pz,
+                         float h_rx, float h_ry, float h_rz, float h_a, float t_lo, float t_hi, bool right_first) {
+    const hyb_f2 ax = hyb_slab(lox, h_rx, h_px), bx = hyb_slab(hix, h_rx, h_px);
+    const hyb_f2 ay = hyb_slab(loy, h_ry, h_py), by = hyb_slab(hiy, h_ry, h_py);
+    const hyb_f2 az = hyb_slab(loz, h_rz, h_pz), bz = hyb_slab(hiz, h_rz, h_pz);
+    float tmn[2], tmx[2];
 #ifdef __HIP_DEVICE_COMPILE__
 #pragma unroll
 #endif
     for (int c = 0; c < 2; c++) {
-        const float tmin = fmaxf(fmaxf(fminf(ax[c], bx[c]), fminf(ay[c], by[c])), fminf(az[c], bz[c]));
-        const float tmax = fminf(fminf(fmaxf(ax[c], bx[c]), fmaxf(ay[c], by[c])), fmaxf(az[c], bz[c]));
+        tmn[c] = fmaxf(fmaxf(fminf(ax[c], bx[c]), fminf(ay[c], by[c])), fminf(az[c], bz[c]));
+        tmx[c] = fminf(fminf(fmaxf(ax[c], bx[c]), fmaxf(ay[c], by[c])), fmaxf(az[c], bz[c]));
+    }
+    HybPair out;
+#ifdef __HIP_DEVICE_COMPILE__
+#pragma unroll
+#endif
+    for (int k = 0; k < 2; k++) {   // 0: the near child, 1: the far one
+        const bool second = right_first ? k == 0 : k == 1;
+        const float tmin = second ? tmn[1] : tmn[0], tmax = second ? tmx[1] : tmx[0];
         const float e0 = fmaf(kHybC, fabsf(tmin), h_a), e1 = fmaf(kHybC, fabsf(tmax), h_a);
         const float tl = tmin - e0, th = tmin + e0, xl = tmax - e1, xh = tmax + e1;
         const bool ordered = th <= xl && xl > kHybEpsUp;           // certainly tmin <= tmax and tmax > EPS
@@ -393,10 +411,13 @@ CRAY_HD HybNode hyb_node(hyb_f2 lox, hyb_f2 loy, hyb_f2 loz, hyb_f2 hix, hyb_f2 
         const float upper = inside ? -3e38f : (front ? th : xh);    // key <= upper when `inside` or `ordered`
         const bool visit = (inside || ordered) && upper < t_lo;     // (t_lo = -inf for a ray.tmax that is NaN or not positive)
         const bool cull = miss || (front && tl >= t_hi);
-        out.s[c] = cull ? kHybCull : (visit ? kHybVisit : kHybResolve);
-        float kc = ordered ? (front ? tmin : -tmax) : __builtin_nanf("");
-        kc = inside ? -1e-30f : kc;
-        out.kc[c] = miss ? __builtin_huge_valf() : kc;
+        if (k == 0) { out.visit_n = visit; out.cull_n = cull; }   // (cull is looked at first by every user)
+        else {
+            out.visit_f = visit; out.cull_f = cull;
+            float kc = ordered ? (front ? tmin : -tmax) : __builtin_nanf("");
+            kc = inside ? -1e-30f : kc;
+            out.kc_f = miss ? __builtin_huge_valf() : kc;
+        }
     }
     return out;
 }
