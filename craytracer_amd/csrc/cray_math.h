@@ -271,15 +271,16 @@ CRAY_HD double canonical_key(double code) { return code != code ? inf64() : (cod
 //
 // Notation: u = 2^-24.  For a ray inside hyb_ray_ok's range and a scene whose bounds are within 2^40:
 //   b32 = the f64 bound b rounded outward to f32            |b32 - b| <= 2u|b|        (k_make_inner32)
-//   o32 = RN32(o_i),  r32 = RN32(RN64(1/d_i))               |o32 - o| <= u|o|,  |r32 d - 1| <= u(1 + 2^-28)
-//   qt  = RN32(RN32(b32 - o32) * r32)                       the f32 slab quotient
+//   r32 = RN32(RN64(1/d_i)),  p32 = RN32(RN64(o_i * RN64(1/d_i)))      |r32 d - 1| <= u(1 + 2^-28),  |p32 d / o - 1| <= u(1 + 2^-27)
+//   qt  = RN32(b32 * r32 - p32)                             the f32 slab quotient: ONE fma (round 4; rounds 2-3: (b32 - o32) * r32)
 //   q   = RN64(RN64(b - o) / d)                             the reference's quotient (= div_fast, exactly)
-// With Q = (b - o)/d:  qt - q = Q[(1+d1)(1+d2)(1+rho) - (1+e1)(1+e2)] + ((b32-b) - (o32-o))/d (1+d1)(1+d2)(1+rho), hence, using
-// |b| <= |b - o| + |o|,        |qt - q| <= 5.02u |qt| + 3.02u |o_i| / |d_i|.
-// f+-(x) = x +- (a + c|x|) with c = 8u, a = 4u(1 + 2^-10) max_i |o_i| |1/d_i| (>= 2^-100: absorbs f32 underflow) are increasing,
+// With Q = (b - o)/d:  b32 r32 - p32 = Q + (b/d)(beta + rho + beta rho) - (o/d) pi  with |beta| <= 2u, |rho|, |pi| <= u(1 + 2^-27), and
+// |b/d| <= |Q| + |o/d|; the fma rounds once more (1 + delta, |delta| <= u) and q = Q(1 + 2^-52), hence
+//        |qt - q| <= 4.01u |qt| + 4.01u |o_i| / |d_i|.
+// f+-(x) = x +- (a + c|x|) with c = 8u, a = 5u max_i |o_i| |1/d_i| (>= 2^-100: absorbs f32 underflow of qt and p32) are increasing,
 // so min / max over the axes commute with them:
 //   tmin in [f-(tmin32), f+(tmin32)],  tmax in [f-(tmax32), f+(tmax32)],   tmin32 / tmax32 = the plain f32 slab results.
-// The spare 2.98u|x| and 0.98u|o|/|d| cover the roundings of evaluating f+- themselves in f32.
+// The spare 3.99u|x| and 0.99u|o|/|d| cover the roundings of evaluating f+- themselves in f32 (and of a).
 //
 // hyb_key classifies a box from the two enclosures (tl,th), (xl,xh) and returns an ENCODED key estimate kc:
 //   +inf    certainly no intersection (tmin > tmax, or tmax < 0)                      key = +inf
@@ -330,7 +331,7 @@ CRAY_HD HybRay hyb_ray(vec3 o, vec3 d, vec3 rd, bool fast_div) {
     const bool ok = fast_div && ax >= 0x1p-30 && ax <= 0x1p30 && ay >= 0x1p-30 && ay <= 0x1p30 && az >= 0x1p-30 && az <= 0x1p30 &&
                     fabs(o.x) <= 0x1p40 && fabs(o.y) <= 0x1p40 && fabs(o.z) <= 0x1p40;
     const double m = fmax(fmax(fabs(o.x) * fabs(rd.x), fabs(o.y) * fabs(rd.y)), fabs(o.z) * fabs(rd.z));
-    const float a = (float)(m * (0x1p-22 * (1.0 + 0x1p-10)));
+    const float a = (float)(m * 0x1.4p-22);   // 5u
     h.a = ok ? fmaxf(a, 0x1p-100f) : __builtin_nanf("");
     return h;
 }
@@ -358,7 +359,9 @@ CRAY_HD float hyb_key(const float* lo, const float* hi, const HybRay& h) {
 CRAY_HD int hyb_status(float kc, float a, float t_lo, float t_hi) {   // a popped entry against the current ray.tmax; no branches
     const float m = fabsf(kc), e = fmaf(kHybC, m, a);
     const bool visit = m + e < t_lo;
-    const bool cull = kc == __builtin_huge_valf() || (kc > 0.0f && m - e >= t_hi);
+    // (kc = +inf, "certainly no intersection": m - e is inf - inf = NaN, so `not below t_hi` holds without a comparison of its own;
+    // t_hi is never NaN)
+    const bool cull = kc > 0.0f && !(m - e < t_hi);
     return cull ? kHybCull : (visit ? kHybVisit : kHybResolve);
 }
 
