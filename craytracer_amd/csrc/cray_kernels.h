@@ -122,8 +122,12 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
     // Traversal stack: the bottom kLdsStack entries of every lane live in LDS ([entry][thread], so a
     // wave's access is conflict-free), deeper entries (rare) spill to scratch.  An entry is 12 B: the child reference and its
     // f64 key, or (HYB) the reference, the encoded f32 key estimate and parent | side << 31 for a later exact test.
-    __shared__ uint32_t lds_ref[kLdsStack * kBlock];
-    __shared__ uint32_t lds_kw[kLdsStack * kBlock * 2];   // f64 key as two words [2 sp][thread] / [2 sp + 1][thread]; HYB: key, parent
+    // (one array [entry][word][thread] — reference, f64 key as two words / HYB: key estimate, parent — so that the pop loop walks
+    // it with ONE address register and immediate offsets)
+    __shared__ uint32_t lds_st[kLdsStack * 3 * kBlock];
+#define CRAY_LDS_REF(i_, t_) lds_st[((i_) * 3) * kBlock + (t_)]
+#define CRAY_LDS_W0(i_, t_) lds_st[((i_) * 3 + 1) * kBlock + (t_)]
+#define CRAY_LDS_W1(i_, t_) lds_st[((i_) * 3 + 2) * kBlock + (t_)]
     uint32_t sref[kStackDepth - kLdsStack];
     uint32_t skw0[kStackDepth - kLdsStack], skw1[kStackDepth - kLdsStack];
     const unsigned int tid = threadIdx.x;
@@ -162,7 +166,7 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
     // (r_: reference, w0_ / w1_: the two payload words)
 #define CRAY_PUSH_W(r_, w0_, w1_)                                                          \
     do {                                                                                   \
-        if (sp < kLdsStack) { lds_ref[sp * kBlock + tid] = (r_); lds_kw[(2 * sp) * kBlock + tid] = (w0_); lds_kw[(2 * sp + 1) * kBlock + tid] = (w1_); sp++; } \
+        if (sp < kLdsStack) { CRAY_LDS_REF(sp, tid) = (r_); CRAY_LDS_W0(sp, tid) = (w0_); CRAY_LDS_W1(sp, tid) = (w1_); sp++; } \
         else if (sp < kStackDepth) { sref[sp - kLdsStack] = (r_); skw0[sp - kLdsStack] = (w0_); skw1[sp - kLdsStack] = (w1_); sp++; }      \
         else if (sp < kStackDepth + (int)ctr->deep_depth) {                                \
             const size_t at_ = (size_t)(sp - kStackDepth) * ((size_t)gridDim.x * kBlock) + (size_t)blockIdx.x * kBlock + tid; \
@@ -174,7 +178,7 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
 #define CRAY_PUSH_H(r_, kc_, par_) CRAY_PUSH_W(r_, __float_as_uint(kc_), (par_))
 #define CRAY_POP_W(r_, w0_, w1_)                                                           \
     do {                                                                                   \
-        if (sp < kLdsStack) { r_ = lds_ref[sp * kBlock + tid]; w0_ = lds_kw[(2 * sp) * kBlock + tid]; w1_ = lds_kw[(2 * sp + 1) * kBlock + tid]; } \
+        if (sp < kLdsStack) { r_ = CRAY_LDS_REF(sp, tid); w0_ = CRAY_LDS_W0(sp, tid); w1_ = CRAY_LDS_W1(sp, tid); } \
         else if (sp < kStackDepth) { r_ = sref[sp - kLdsStack]; w0_ = skw0[sp - kLdsStack]; w1_ = skw1[sp - kLdsStack]; }               \
         else {                                                                             \
             const size_t at_ = (size_t)(sp - kStackDepth) * ((size_t)gridDim.x * kBlock) + (size_t)blockIdx.x * kBlock + tid; \
@@ -265,6 +269,9 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
 #undef CRAY_PUSH_H
 #undef CRAY_PUSH_W
 #undef CRAY_POP_W
+#undef CRAY_LDS_REF
+#undef CRAY_LDS_W0
+#undef CRAY_LDS_W1
 #undef CRAY_ANY_LANE
 }
 
