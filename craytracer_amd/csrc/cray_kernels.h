@@ -128,8 +128,7 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
 #define CRAY_LDS_REF(i_, t_) lds_st[((i_) * 3) * kBlock + (t_)]
 #define CRAY_LDS_W0(i_, t_) lds_st[((i_) * 3 + 1) * kBlock + (t_)]
 #define CRAY_LDS_W1(i_, t_) lds_st[((i_) * 3 + 2) * kBlock + (t_)]
-    uint32_t sref[kStackDepth - kLdsStack];
-    uint32_t skw0[kStackDepth - kLdsStack], skw1[kStackDepth - kLdsStack];
+    uint32_t sst[(kStackDepth - kLdsStack) * 3];   // (scratch level: the three words of an entry side by side, one address, one load)
     const unsigned int tid = threadIdx.x;
     // work sharing in the drain (STEAL): per ray that has been split — indexed by the thread that fetched it from the queue, its
     // "owner" — the number of workers still walking and whether one of them found an occluder; `steal_pair` matches the k-th idle
@@ -167,7 +166,7 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
 #define CRAY_PUSH_W(r_, w0_, w1_)                                                          \
     do {                                                                                   \
         if (sp < kLdsStack) { CRAY_LDS_REF(sp, tid) = (r_); CRAY_LDS_W0(sp, tid) = (w0_); CRAY_LDS_W1(sp, tid) = (w1_); sp++; } \
-        else if (sp < kStackDepth) { sref[sp - kLdsStack] = (r_); skw0[sp - kLdsStack] = (w0_); skw1[sp - kLdsStack] = (w1_); sp++; }      \
+        else if (sp < kStackDepth) { sst[(sp - kLdsStack) * 3] = (r_); sst[(sp - kLdsStack) * 3 + 1] = (w0_); sst[(sp - kLdsStack) * 3 + 2] = (w1_); sp++; }      \
         else if (sp < kStackDepth + (int)ctr->deep_depth) {                                \
             const size_t at_ = (size_t)(sp - kStackDepth) * ((size_t)gridDim.x * kBlock) + (size_t)blockIdx.x * kBlock + tid; \
             ctr->deep_ref[at_] = (r_);                                                     \
@@ -179,7 +178,7 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& 
 #define CRAY_POP_W(r_, w0_, w1_)                                                           \
     do {                                                                                   \
         if (sp < kLdsStack) { r_ = CRAY_LDS_REF(sp, tid); w0_ = CRAY_LDS_W0(sp, tid); w1_ = CRAY_LDS_W1(sp, tid); } \
-        else if (sp < kStackDepth) { r_ = sref[sp - kLdsStack]; w0_ = skw0[sp - kLdsStack]; w1_ = skw1[sp - kLdsStack]; }               \
+        else if (sp < kStackDepth) { r_ = sst[(sp - kLdsStack) * 3]; w0_ = sst[(sp - kLdsStack) * 3 + 1]; w1_ = sst[(sp - kLdsStack) * 3 + 2]; }               \
         else {                                                                             \
             const size_t at_ = (size_t)(sp - kStackDepth) * ((size_t)gridDim.x * kBlock) + (size_t)blockIdx.x * kBlock + tid; \
             const double dk_ = ctr->deep_key[at_];                                         \
