@@ -78,8 +78,23 @@ constexpr uint32_t kTraceLdsShapes = 8;   // sphere + disk records (272 B each) 
 //               part again itself, at its place in the order and with the tmax the fold has reached: the reference's own walk
 //               of it.  Helpers do not hand work on.
 enum : uint32_t { kTfThief = 1u, kTfMono = 2u, kTfCert = 4u, kTfWait = 8u, kTfNoDonate = 16u };   // + bits 8..10 helpers so far, 12..13 this helper's slot
+// The path state's ~30 array pointers are needed when a lane takes a ray or hands back a result — once in thirty to fifty
+// iterations.  Held in scalar registers for the whole loop (a kernel argument passed by value is loaded once, at the top) they
+// pushed the pointers the loop needs in EVERY iteration out into lanes of a vector register, a v_readlane each time.  So the
+// body reads them where it needs them, from the kernel-argument segment itself: ps_here() makes the pointer opaque to the
+// compiler at that place, which keeps the loads there instead of hoisted in front of the loop.
+typedef const PathState __attribute__((address_space(4))) * PsArg;
+__device__ __forceinline__ PsArg ps_here(PsArg a) {
+    asm volatile("" : "+s"(a));
+    return a;
+}
+// (k_trace and k_trace_mixed both start with DevScene sc, PathState ps)
+constexpr size_t kPsArgOffset = (sizeof(DevScene) + alignof(PathState) - 1) / alignof(PathState) * alignof(PathState);
+__device__ __forceinline__ PsArg ps_kernarg() {
+    return (PsArg)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + kPsArgOffset);
+}
 template <int MODE, bool COUNT, int HYB, bool SHAPES_LDS = false, bool TAIL = false>
-__device__ __forceinline__ void trace_body(const DevScene& sc, const PathState& ps, const uint32_t* __restrict__ queue, const uint32_t n_first,
+__device__ __forceinline__ void trace_body(const DevScene& sc, const PsArg ps_arg, const uint32_t* __restrict__ queue, const uint32_t n_first,
                                            const uint32_t* __restrict__ queue_b, const uint32_t n_b, const double* __restrict__ closest_tmax,
                                            Counters* ctr, unsigned int* work_head, unsigned int refill_min) {
     static_assert(!(COUNT && MODE == kTraceMixed), "traversal counting uses the separate launches");
@@ -278,7 +293,7 @@ template <bool ANY, bool COUNT, int HYB, bool SHAPES_LDS = false>
 __global__ void CRAY_TRACE_EU __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace(DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
                                                   const unsigned int* __restrict__ n_ptr, uint32_t n_fixed,
                                                   const double* __restrict__ closest_tmax, Counters* ctr, unsigned int* work_head, unsigned int refill_min) {
-    trace_body<ANY ? kTraceAny : kTraceClosest, COUNT, HYB, SHAPES_LDS>(sc, ps, queue, n_ptr ? *n_ptr : n_fixed, nullptr, 0u, closest_tmax, ctr, work_head, refill_min);
+    trace_body<ANY ? kTraceAny : kTraceClosest, COUNT, HYB, SHAPES_LDS>(sc, ps_kernarg(), queue, n_ptr ? *n_ptr : n_fixed, nullptr, 0u, closest_tmax, ctr, work_head, refill_min);
 }
 
 // shadow rays of one bounce (any_queue) + path segments of the next (closest_queue) in one persistent launch
@@ -287,7 +302,7 @@ __global__ void CRAY_TRACE_EU __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trac
                                                   const unsigned int* __restrict__ n_any_ptr, const uint32_t* __restrict__ closest_queue,
                                                   const unsigned int* __restrict__ n_closest_ptr, Counters* ctr, unsigned int* work_head,
                                                   unsigned int refill_min) {
-    trace_body<kTraceMixed, false, HYB, SHAPES_LDS, TAIL>(sc, ps, any_queue, *n_any_ptr, closest_queue, *n_closest_ptr, nullptr, ctr, work_head, refill_min);
+    trace_body<kTraceMixed, false, HYB, SHAPES_LDS, TAIL>(sc, ps_kernarg(), any_queue, *n_any_ptr, closest_queue, *n_closest_ptr, nullptr, ctr, work_head, refill_min);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
