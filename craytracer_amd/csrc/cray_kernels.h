@@ -742,6 +742,11 @@ __global__ void __launch_bounds__(kBlock, shade_waves(F, MODE)) k_shade(DevScene
                                                   uint32_t uni_nx, uint32_t uni_ny, const uint32_t* __restrict__ pix_list, uint32_t px0, uint64_t seed) {
     constexpr bool kSimple = (MODE & kModeSimple) != 0, kUniform = (MODE & kModeUniform) != 0, kIndependent = (MODE & kModeIndependent) != 0;
     const uint32_t n = n_ptr ? *n_ptr : n_fixed;
+    // (the two path-state views — sixty array pointers — are read from the kernel-argument segment where a path uses them, as
+    // in trace_body: held in scalar registers across the tile loop they were spilled into vector-register lanes, 343 v_readlane
+    // and 222 v_writelane in this kernel)
+    const PsArg ps_arg = ps_kernarg();
+    const PsArg po_arg = (PsArg)((const char __attribute__((address_space(4)))*)ps_arg + sizeof(PathState));
     // `ps` is the state of this bounce (live slots named by `queue`, or the identity at bounce 0), `po` the view the survivors
     // are written to: the OTHER live buffer, the shadow buffer and L (cray_device.h).  A block walks tiles of `tsz` queue
     // positions; a survivor's new live slot is tile * tsz + its rank among the tile's survivors (one LDS atomic per wave), its
@@ -810,16 +815,17 @@ __global__ void __launch_bounds__(kBlock, shade_waves(F, MODE)) k_shade(DevScene
         bool skip_shadow = false, was_hit = false;
         if (i < n) {
             const uint32_t p = queue ? queue[i] : i;        // live slot of this bounce
-            const uint32_t p0 = queue ? ps.p0[p] : i;       // original path: L, the Sobol sample index, the pixel
+            const PsArg psk = ps_here(ps_arg);
+            const uint32_t p0 = queue ? psk->p0[p] : i;       // original path: L, the Sobol sample index, the pixel
             // L is read and written only by the paths that add emission in this bounce (a light was hit or the ray
             // escaped to an Infinite light); for all others the 48 B of traffic per path are skipped
             rgb L = mkc(0, 0, 0);
             bool L_loaded = false;
             auto add_L = [&](rgb term) {
-                if (!L_loaded) { L = mkc(po.lr[p0], po.lg[p0], po.lb[p0]); L_loaded = true; }
+                if (!L_loaded) { const PsArg pok = ps_here(po_arg); L = mkc(pok->lr[p0], pok->lg[p0], pok->lb[p0]); L_loaded = true; }
                 L = L + term;
             };
-            const int32_t hp = ps.hprim[p];
+            const int32_t hp = psk->hprim[p];
             // path state is loaded where it is first needed: an escaped path needs none of it unless the scene has an
             // Infinite light, prev_pdf / the specular flag only matter where emission is weighted
             rgb beta = mkc(0, 0, 0);
@@ -833,9 +839,9 @@ __global__ void __launch_bounds__(kBlock, shade_waves(F, MODE)) k_shade(DevScene
                     const DevLight& l = sc.lights[li];
                     if (l.kind != CRAY_LIGHT_INFINITE) continue;
                     if (!state_loaded) {
-                        beta = bounce == 0 ? mkc(1, 1, 1) : mkc(ps.br[p], ps.bg[p], ps.bb[p]);
-                        prev_pdf = bounce == 0 ? 0.0 : ps.prev_pdf[p];
-                        specular_bounce = bounce == 0 || (ps.flags[p] & 1u) != 0;
+                        beta = bounce == 0 ? mkc(1, 1, 1) : mkc(psk->br[p], psk->bg[p], psk->bb[p]);
+                        prev_pdf = bounce == 0 ? 0.0 : psk->prev_pdf[p];
+                        specular_bounce = bounce == 0 || (psk->flags[p] & 1u) != 0;
                         state_loaded = true;
                     }
                     rgb Le = mkc(l.c[0], l.c[1], l.c[2]);
@@ -847,21 +853,21 @@ __global__ void __launch_bounds__(kBlock, shade_waves(F, MODE)) k_shade(DevScene
                         add_L(beta * Le * w);
                     }
                 }
-                if (L_loaded) { po.lr[p0] = L.r; po.lg[p0] = L.g; po.lb[p0] = L.b; }
+                if (L_loaded) { const PsArg pok = ps_here(po_arg); pok->lr[p0] = L.r; pok->lg[p0] = L.g; pok->lb[p0] = L.b; }
             } else {
                 was_hit = true;
-                const ray_t ray = mkray(mk(ps.ox[p], ps.oy[p], ps.oz[p]), mk(ps.dx[p], ps.dy[p], ps.dz[p]));
+                const ray_t ray = mkray(mk(psk->ox[p], psk->oy[p], psk->oz[p]), mk(psk->dx[p], psk->dy[p], psk->dz[p]));
                 const vec3 w_o = flip(ray.d);
-                beta = bounce == 0 ? mkc(1, 1, 1) : mkc(ps.br[p], ps.bg[p], ps.bb[p]);  // camera rays: beta = WHITE
+                beta = bounce == 0 ? mkc(1, 1, 1) : mkc(psk->br[p], psk->bg[p], psk->bb[p]);  // camera rays: beta = WHITE
                 const cray_prim pr = sc.prims[hp];
                 const int32_t mat = pr.light >= 0 ? -1 : pr.material;
                 const bool need_uv = CRAY_HAS(F, SF_TEX_CHECKER | SF_TEX_IMAGE) && mat >= 0 && sc.materials[mat].pad_ != 0;
-                const SurfPoint sp = surface_at<F>(sc, pr, ray, ps.ht[p], ps.hu[p], ps.hv[p], need_uv);
+                const SurfPoint sp = surface_at<F>(sc, pr, ray, psk->ht[p], psk->hu[p], psk->hv[p], need_uv);
                 const vec3 n_s = sp.normal, x = sp.location;
 
                 // PathSegmentSamples::from (path_integrator.rs:26-36): dims 4+8k .. 11+8k
                 const uint32_t sidx = s_lo + p0 % spp_pass;
-                const uint32_t h = ps.hash[p];
+                const uint32_t h = psk->hash[p];
                 double sa[4], sb[4];
                 if (kIndependent) {  // IndependentSampler: draws 4 + 8 b .. (4 + 7 b .. for simple_integrator) of the pixel sample's generator
                     const uint32_t pix = pix_list[px0 + p0 / spp_pass];
@@ -903,13 +909,13 @@ __global__ void __launch_bounds__(kBlock, shade_waves(F, MODE)) k_shade(DevScene
                     const DevLight& l = sc.lights[pr.light];
                     rgb Le = mkc(l.c[0], l.c[1], l.c[2]);
                     if (!black(Le)) {
-                        specular_bounce = bounce == 0 || (ps.flags[p] & 1u) != 0;  // camera rays count as specular (:50)
+                        specular_bounce = bounce == 0 || (psk->flags[p] & 1u) != 0;  // camera rays count as specular (:50)
                         if (specular_bounce) {
                             add_L(beta * Le);
                         } else if (!kSimple) {  // simple_integrator.rs:84-86 has no MIS branch
                             double lp = light_shape_pdf_from<F>(sc, l, x, n_s, w_o);
                             double light_pdf = lp * light_select_pdf(sc, (uint32_t)sc.first_equal_light[pr.light]);
-                            prev_pdf = ps.prev_pdf[p];  // bounce > 0 here
+                            prev_pdf = psk->prev_pdf[p];  // bounce > 0 here
                             double w = power_heuristic(light_pdf, prev_pdf);
                             add_L(beta * Le * w);
                         }
@@ -983,11 +989,12 @@ __global__ void __launch_bounds__(kBlock, shade_waves(F, MODE)) k_shade(DevScene
                     skip_shadow = queried && !want_shadow;
                     if (want_shadow) {
                         const uint32_t q = tile_base + lds_reserve(&c_shadow);   // shadow slot: contiguous per tile
-                        po.sox[q] = x.x; po.soy[q] = x.y; po.soz[q] = x.z;
-                        po.sdx[q] = w_i.x; po.sdy[q] = w_i.y; po.sdz[q] = w_i.z;
-                        po.stmax[q] = s_tmax;
-                        po.cr[q] = contrib.r; po.cg[q] = contrib.g; po.cb[q] = contrib.b;
-                        po.sp0[q] = p0; po.sprim[q] = hp;
+                        const PsArg pok = ps_here(po_arg);
+                        pok->sox[q] = x.x; pok->soy[q] = x.y; pok->soz[q] = x.z;
+                        pok->sdx[q] = w_i.x; pok->sdy[q] = w_i.y; pok->sdz[q] = w_i.z;
+                        pok->stmax[q] = s_tmax;
+                        pok->cr[q] = contrib.r; pok->cg[q] = contrib.g; pok->cb[q] = contrib.b;
+                        pok->sp0[q] = p0; pok->sprim[q] = hp;
                     }
                 }
 
@@ -1019,15 +1026,16 @@ __global__ void __launch_bounds__(kBlock, shade_waves(F, MODE)) k_shade(DevScene
                     // the loop condition of the next iteration (:54)
                     go = (bounce + 1 < sc.max_depth) && !black(beta);
                 }
-                if (L_loaded) { po.lr[p0] = L.r; po.lg[p0] = L.g; po.lb[p0] = L.b; }
+                if (L_loaded) { const PsArg pok = ps_here(po_arg); pok->lr[p0] = L.r; pok->lg[p0] = L.g; pok->lb[p0] = L.b; }
                 if (go) {
                     const uint32_t q = tile_base + lds_reserve(&c_next);   // live slot of the next bounce: contiguous per tile
-                    po.ox[q] = x.x; po.oy[q] = x.y; po.oz[q] = x.z;  // Ray::new(location, w_i): no offset
-                    po.dx[q] = ls.w_i.x; po.dy[q] = ls.w_i.y; po.dz[q] = ls.w_i.z;
-                    po.br[q] = beta.r; po.bg[q] = beta.g; po.bb[q] = beta.b;
-                    po.prev_pdf[q] = bsdf_pdf;
-                    po.flags[q] = ls.specular ? 1u : 0u;
-                    po.hash[q] = h; po.p0[q] = p0; po.hprim[q] = hp;
+                    const PsArg pok = ps_here(po_arg);
+                    pok->ox[q] = x.x; pok->oy[q] = x.y; pok->oz[q] = x.z;  // Ray::new(location, w_i): no offset
+                    pok->dx[q] = ls.w_i.x; pok->dy[q] = ls.w_i.y; pok->dz[q] = ls.w_i.z;
+                    pok->br[q] = beta.r; pok->bg[q] = beta.g; pok->bb[q] = beta.b;
+                    pok->prev_pdf[q] = bsdf_pdf;
+                    pok->flags[q] = ls.specular ? 1u : 0u;
+                    pok->hash[q] = h; pok->p0[q] = p0; pok->hprim[q] = hp;
                 }
             }
         }
