@@ -313,6 +313,42 @@ __device__ __forceinline__ bool tri_test(vec3 v0, vec3 e1, vec3 e2, const ray_t&
     return in_range(ray, t);
 }
 
+// The same test with the reciprocal of the denominator formed once for its (up to) three quotients.  A true f64 division is
+// v_div_scale (denominator), v_rcp, two Newton steps (4 fma), v_div_scale (numerator), q = n' y, r = n' - d' q, v_div_fmas,
+// v_div_fixup; the first six depend on the numerator only through the scaling v_div_scale may apply to the denominator for
+// extreme operand pairs.  The scaled denominator is formed for each numerator (one instruction) and when it is the one the
+// reciprocal was refined for — always, unless an exponent is extreme — the quotient takes five more instructions instead of ten,
+// bit for bit the compiler's.  A lane where it differs divides plainly.  (Without the early-outs — three quotients side by
+// side for every lane — the mixed launches were 0.9 ms slower: whole waves do fail the first test together.)
+__device__ __forceinline__ bool tri_test_shared(vec3 v0, vec3 e1, vec3 e2, const ray_t& ray, double& t, double& u, double& v) {
+    const vec3 P = cross(ray.d, e2);
+    const double denom = dot(P, e1);
+    if (denom > -kEps && denom < kEps) return false;
+    const vec3 T = ray.o - v0;
+    const double nu = dot(P, T);
+    bool f;
+    const double du = __builtin_amdgcn_div_scale(nu, denom, false, &f);
+    double y = __builtin_amdgcn_rcp(du);
+    y = __builtin_fma(y, __builtin_fma(-du, y, 1.0), y);
+    y = __builtin_fma(y, __builtin_fma(-du, y, 1.0), y);
+    auto quot = [&](double n) {
+        bool fd, fn;
+        const double dn = __builtin_amdgcn_div_scale(n, denom, false, &fd);
+        if (__builtin_bit_cast(unsigned long long, dn) != __builtin_bit_cast(unsigned long long, du)) return n / denom;
+        const double ns = __builtin_amdgcn_div_scale(n, denom, true, &fn);
+        const double q = ns * y;
+        const double r = __builtin_fma(-du, q, ns);
+        return __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(r, y, q, fn), denom, n);
+    };
+    u = quot(nu);
+    if (u < 0.0 || u > 1.0) return false;
+    const vec3 Q = cross(T, e1);
+    v = quot(dot(Q, ray.d));
+    if (v < 0.0 || u + v > 1.0) return false;
+    t = quot(dot(Q, e2));
+    return in_range(ray, t);
+}
+
 // Shape::pdf_from (shape.rs:487-502): re-intersect the light's OWN shape from the shading
 // point; pdf = d^2 / (|w_i . n_x| * area) with n_x the *shading point's* normal (sic).
 template <uint32_t F = SF_ALL>
