@@ -243,6 +243,74 @@ def test_adversarial_rays_bit_exact(name):
     ctx.close()
 
 
+def _needle_rays(rng, v0, e1, e2, n, far):
+    """rays that cross the triangle's plane near v0 + a e1 + b e2 with small a, b — from `far` away along a direction that is not
+    in the plane — and as many that miss on either side"""
+    nrm = np.cross(e1 / np.linalg.norm(e1), e2 / np.linalg.norm(e2))
+    nrm /= np.linalg.norm(nrm)
+    rays = []
+    for _ in range(n):
+        a, b = rng.uniform(-0.2, 0.6, 2)
+        target = v0 + a * e1 + b * e2
+        d = -(nrm + 0.3 * rng.normal(size=3))
+        d /= np.linalg.norm(d)
+        rays.append(np.concatenate([target - d * far, d, [np.inf]]))
+    return np.array(rays)
+
+
+@pytest.mark.parametrize('case', ['ordinary', 'denominator_near_the_top', 'denominator_just_above_epsilon_seen_from_1e280', 'large'])
+def test_triangle_quotients_at_the_ends_of_the_exponent_range(case):
+    """The triangle test's three quotients share one refined reciprocal of their denominator (tri_test_shared, cray_shading.h)
+    when v_div_scale leaves the denominator alone, and fall back to a plain division when it does not.  One-triangle scenes
+    (the tree is a single leaf: every ray runs the test) whose operands reach both: a denominator near 2^1020 (edges of
+    2^620 and 2^400, rays that cross next to the corner), a denominator just above EPSILON under numerators near 1e280
+    (exponent gap > 768), and ordinary ones.  Hits, distances and barycentric-dependent locations must equal the oracle's,
+    whose divisions are the CPU's."""
+    from craytracer_amd import scene as S
+    rng = np.random.default_rng(17)
+    a = rng.normal(size=3); a /= np.linalg.norm(a)
+    b = np.cross(a, rng.normal(size=3)); b /= np.linalg.norm(b)
+    if case == 'ordinary':
+        v0, e1, e2, far = rng.normal(size=3), 3.0 * a + 0.5 * b, 2.0 * b, 7.0
+    elif case == 'large':
+        v0, e1, e2, far = rng.normal(size=3) * 2.0 ** 300, 2.0 ** 300 * (a + 0.2 * b), 2.0 ** 299 * b, 2.0 ** 302
+    elif case == 'denominator_near_the_top':
+        v0, e1, e2, far = rng.normal(size=3), 2.0 ** 620 * a, 2.0 ** 400 * b, 3.0
+    else:
+        v0, e1, e2, far = rng.normal(size=3), 3e-4 * a, 2e-4 * b, 1e280
+    if case == 'denominator_near_the_top':
+        # cross the plane within a few units of the corner: u ~ 2^-620, v ~ 2^-400
+        rays = []
+        nrm = np.cross(a, b)
+        for _ in range(256):
+            target = v0 + rng.uniform(-0.5, 2.0) * a + rng.uniform(-0.5, 2.0) * b
+            d = -(nrm + 0.3 * rng.normal(size=3)); d /= np.linalg.norm(d)
+            rays.append(np.concatenate([target - d * far, d, [np.inf]]))
+        rays = np.array(rays)
+    else:
+        rays = _needle_rays(rng, v0, e1, e2, 256, far)
+    tris = np.array([[v0, v0 + e1, v0 + e2]])
+    white = S.Material.new_matte(S.Color(1, 1, 1), 0.0)
+    cam = S.Camera.perspective(S.Film(8, 8), (-5, 0.2, 0.2), (1, 0.2, 0.2), (0, 1, 0), 20)
+    sc = S.Scene(2, 1, cam, [S.Light.Point((0, 5, 0), S.Color.WHITE)], [S.Mesh(S.triangles_flat(tris), material=white)])
+    ctx = backend.Context(0)
+    dev = ctx.upload(backend.HostScene(sc))
+    orc = ol.OracleScene(sc)
+    g, gst = dev.trace(rays)
+    o, ost = orc.trace(rays)
+    assert np.array_equal(g['hit'], o['hit'])
+    h = o['hit'] != 0
+    assert 20 < int(h.sum()) < len(rays) - 20, int(h.sum())
+    assert np.array_equal(g['t'][h], o['t'][h])
+    assert np.array_equal(g['location'][h], o['location'][h])
+    assert gst['closest_prims'] == ost['closest_prims']
+    ga, _ = dev.trace(rays, any_hit=True)
+    oa, _ = orc.trace(rays, any_hit=True)
+    assert np.array_equal(ga['hit'], oa['hit'])
+    dev.close()
+    ctx.close()
+
+
 def test_ragged_film_and_sample_counts():
     """Film sizes that are no multiple of the 64x64 tile, a sample count that is no multiple of the 8-sample batch,
     and a path pool that cuts both: the film must still be the oracle's, pixel for pixel."""
