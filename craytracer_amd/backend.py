@@ -84,7 +84,7 @@ ABI_SYMBOLS = ['cray_ctx_create', 'cray_ctx_destroy', 'cray_scene_upload', 'cray
                'cray_scene_device_bytes', 'cray_render', 'cray_render_params_default', 'cray_render_samples',
                'cray_trace', 'cray_last_error', 'cray_host_scene_new', 'cray_host_scene_flat',
                'cray_host_scene_build_seconds', 'cray_host_scene_free', 'cray_host_scene_new_on',
-               'cray_host_scene_bvh_seconds', 'cray_bvh_build_sah', 'cray_write_exr', 'cray_read_exr', 'cray_host_sincos', 'cray_host_div_fast_mismatches', 'cray_host_child_key_mismatches', 'cray_host_hyb_key_violations', 'cray_host_sincos_fast_check', 'cray_host_chacha_block', 'cray_host_independent_draws',
+               'cray_host_scene_bvh_seconds', 'cray_bvh_build_sah', 'cray_write_exr', 'cray_read_exr', 'cray_host_sincos', 'cray_host_div_fast_mismatches', 'cray_host_child_key_mismatches', 'cray_host_hyb_key_violations', 'cray_host_tri_cull_violations', 'cray_host_sincos_fast_check', 'cray_host_chacha_block', 'cray_host_independent_draws',
                'cray_cry_tokenize', 'cray_cry_free_tokens', 'cray_cry_parse_value', 'cray_cry_free_string',
                'cray_cry_parse_scene', 'cray_owned_scene_desc', 'cray_owned_scene_warnings', 'cray_owned_scene_free',
                'cray_scene_info', 'cray_comm_unique_id', 'cray_comm_init', 'cray_comm_rank', 'cray_comm_world_size',
@@ -194,6 +194,9 @@ def lib():
     if hasattr(L, 'cray_host_hyb_key_violations'):   # an older experimental build (CRAY_LIB) may lack it
         L.cray_host_hyb_key_violations.restype = C.c_uint64
         L.cray_host_hyb_key_violations.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    if hasattr(L, 'cray_host_tri_cull_violations'):
+        L.cray_host_tri_cull_violations.restype = C.c_uint64
+        L.cray_host_tri_cull_violations.argtypes = [C.c_void_p] * 6 + [C.c_uint64, C.c_void_p]
     _lib = L
     return L
 

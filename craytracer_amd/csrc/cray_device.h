@@ -14,6 +14,8 @@
 //    bounds k_shade at the later bounces).  Shadow rays get their own compacted buffer; L stays per original path.
 #pragma once
 
+#include <cstddef>
+
 #include "../../include/cray.h"
 #include "cray_math.h"
 
@@ -80,14 +82,36 @@ struct alignas(64) InnerNodeH {
     uint32_t ref0, ref1, axis, pad_;
 };
 static_assert(sizeof(InnerNodeH) == 64, "InnerNodeH is four 16-B loads");
-// ---- pair lines (round 4, CRAY_HYBRID=2): what binds the exact traversal is the number of 128-B LINES a compute unit can fill
-// per clock, and a 64-B record fetched alone still fills a whole line.  Here a node's line also holds the record
-// of ONE of its interior children (`comp`): a lane that descends into that child straight away takes the record from the
-// registers it has just loaded and fetches nothing in its next step.  self.pad_ says which child: 0 none, 1 child 0, 2 child 1.
-struct alignas(128) InnerNodeP {
-    InnerNodeH self, comp;
+// ---- round 5: the certified-f32 records of a scene live in ONE arena and a child reference of an InnerNodeH IS the byte offset (a
+// multiple of 16) of what a lane fetches next, | kHLeaf | (count - 1) for a leaf (count in 1..8): the fetch address of every common
+// traversal state is arena + (ref & ~15) — one instruction.  Regions of the arena:
+//     I   n_inner InnerNodeH (64 B)
+//     C   one LeafCullH (64 B) per leaf slot — only when the launches cull triangles from their f32 copies first (DevScene::arena_cull):
+//         the f64 v0 (the culling subtracts it from the origin in f64, cray_math.h tri_cull32), RN32 of the edges, their max-norms
+//         rounded up, the id words
+//     X   one LeafExactH per leaf slot: the f64 triangle of the exact test, 80 B — at a 128-B stride (one line per record) next to a C
+//         region, packed at 80 B without one
+//     R   a copy of inner[] (128 B per interior node): the f64 bounds a RESOLVE step reads
+// A leaf reference names the leaf's first C record (arena_cull) or X record; the X record of the slot whose C record sits at offset c
+// is at 2 c + DevScene::arena_xk (both regions are indexed by slot, strides 64 and 128).
+constexpr uint32_t kHLeaf = 8u;
+CRAY_HD bool href_is_leaf(uint32_t r) { return (r & kHLeaf) != 0; }
+CRAY_HD uint32_t href_off(uint32_t r) { return r & ~15u; }
+CRAY_HD uint32_t href_more(uint32_t r) { return r & 7u; }   // slots of the leaf after this one
+struct alignas(16) LeafCullH {
+    uint32_t prim, kind;
+    double v0[3];               // (sphere / disk slots: the shape index in the bits of v0[0], the rest zero)
+    float e1f[3], e2f[3];       // RN32 of the edges
+    float e1m, e2m;             // max |e1_i|, max |e2_i| of the f64 edges, rounded UP
 };
-static_assert(sizeof(InnerNodeP) == 128, "InnerNodeP is one 128-B line");
+static_assert(sizeof(LeafCullH) == 64, "LeafCullH is four 16-B loads");
+struct alignas(16) LeafExactH {
+    double e1[3], e2[3];
+    uint32_t prim, kind;
+    double v0[3];
+};
+static_assert(sizeof(LeafExactH) == 80, "LeafExactH is five 16-B loads");
+constexpr uint32_t kLeafCullStride = 64u, kLeafExactStride = 128u, kLeafExactPacked = 80u;
 
 struct TriShade {
     double n0[3], n01[3], n02[3];
@@ -117,12 +141,14 @@ struct DevScene {
     // BVH
     double root_lo[3], root_hi[3];
     uint32_t root_ref, n_inner;
-    uint32_t bounds_in_div_range, pad_div_;  // every node bound is 0 or within [2^-500, 2^500]: div_fast is exact
+    uint32_t bounds_in_div_range;  // every node bound is 0 or within [2^-500, 2^500]: div_fast is exact
+    uint32_t root_ref_h;           // root_ref in the arena's encoding (set with innerh)
+    uint32_t arena_xk, arena_xstep;   // X record of the slot with C record at c: 2 c + arena_xk; bytes from an X record to the next
+    uint32_t arena_rbase, pad_arena_; // region R: a copy of inner[] (the f64 bounds of a RESOLVE), so that every fetch is arena + 32-bit offset
     const InnerNode* inner;
     const LeafSlot* slots;
     const InnerNode32* inner32;   // fast mode only (built on first use)
-    const InnerNodeH* innerh;     // certified f32 culling only (built on first use)
-    const InnerNodeP* innerp;     // certified f32 culling with pair lines (built on first use)
+    const InnerNodeH* innerh;     // certified f32 culling only (built on first use): the ARENA — n_inner InnerNodeH, then n_slots LeafRecH
     const LeafSlot32* slots32;
     // primitives
     const cray_prim* prims;
@@ -137,7 +163,8 @@ struct DevScene {
     const uint8_t* pool;
     const double* gamma_lut;  // (c/255)^2.2 for c in 0..255 (Color::from_rgb, color.rs:39-46)
     uint32_t n_materials, n_bxdfs, n_textures, n_images, n_spheres, n_disks;
-    uint32_t shade_stage_shapes, pad_tab_;   // the sphere / disk tables fit the staging area as well
+    uint32_t shade_stage_shapes;   // the sphere / disk tables fit the staging area as well
+    uint32_t arena_cull;           // the arena has a C region and its leaf references point into it: the launches cull triangles from f32 copies first
     uint32_t shade_tables_bytes;  // > 0: materials + bxdfs + textures + lights + light tables fit k_shade's LDS staging area (bytes)
     // lights
     const DevLight* lights;

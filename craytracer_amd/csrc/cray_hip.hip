@@ -65,6 +65,9 @@ struct cray_ctx {
     // (profiles/r04_refill_sweep_f32_culling*.log)
     unsigned int refill_min_hyb = 20, refill_min_any_hyb = 20;
     unsigned int leaf_min = 10;    // lanes of a wave that must be at a leaf slot before the leaf step runs (mixed / any-hit launches; 0 or 1: no waiting)
+    // the same for the two leaf states of the certified-f32 launches (cray_trace_step_hyb.inc): the f32 culling of a slot, the exact test
+    unsigned int cull_min = 6, exact_min = 10;
+    unsigned int tri_cull = 0;     // CRAY_TRI_CULL=0: no f32 culling of triangles, a lane at a leaf slot runs the f64 test at once (read when a scene's arena is built)
     unsigned int lds_shapes = 1;   // the few sphere / disk records of a scene staged in LDS by the traversal launches (CRAY_LDS_SHAPES=0: read global memory)
     unsigned int steal = 1;   // work sharing among the lanes of a wave in the drain of the shadow-ray launches (trace_body, STEAL); CRAY_STEAL=0 turns it off
     int trace_blocks_per_cu = 4;
@@ -89,11 +92,10 @@ struct cray_ctx {
     double* deep_key = nullptr;
     unsigned int deep_depth = 0;
     size_t deep_threads = 0;
-    int hybrid = -1;    // records the exact traversal reads: 0 f64, 1 certified f32 culling (same results), 2 the same with
-                        // pair lines; -1 (default) = per scene and per launch kind, whichever of 0 / 1 the first two frames show to be
-                        // faster (render_local).  CRAY_HYBRID=0/1/2 pins it.
+    int hybrid = -1;    // records the exact traversal reads: 0 f64, 1 certified f32 culling (same results); -1 (default) =
+                        // per scene and per launch kind, whichever the scene's probe passes show to be faster (choose_trace_records).
+                        // CRAY_HYBRID=0/1 pins it.
     int records_b0 = -1, records_rest = -1;   // CRAY_RECORDS_B0 / CRAY_RECORDS_REST (0 / 1): pin the records per launch kind instead of timing
-    int pair_pick = 0;  // pair lines: which interior child shares its parent's line (0 left first, 1 larger surface area)
     int mix_trace = 1;  // shadow rays of bounce b and segments of bounce b+1 in one launch (CRAY_MIX_TRACE=0 disables)
     int log_queues = 0; // CRAY_LOG_QUEUES=1 (diagnostics): after every bounce, sync and print the queue lengths to stderr
     Counters* counters = nullptr;
@@ -147,15 +149,16 @@ struct cray_scene {
     uint32_t features = SF_ALL;  // what the scene can make k_shade do (cray_shading.h)
     int shade_variant = kNumShadeVariants - 1;
     bool hybrid_ok = false;  // the scene is inside the range the certified f32 culling is proven for (cray_math.h hyb_scene_ok)
-    // Which records the traversal launches of this scene read (0 f64, 1 certified f32 culling, 2 pair lines): the bounce-0 launch
-    // (coherent camera rays) and the others separately.  Both kinds of records give the reference's hits bit for bit, so the
-    // choice is a matter of speed only and it depends on the scene: on the dragon the f32 culling is 3-5 % faster in both
-    // kinds, in the Cornell box (axis-aligned boxes: most decisions need the exact retake) 35 % slower, in the staircase
-    // interior 12 % faster for camera rays and 4 % slower for the rest.  With ctx->hybrid = -1 the first frame of a scene that
-    // is big enough to time runs on f64 records, the second on f32 culling, and the faster one per kind is kept.
+    // Which records the traversal launches of this scene read (0 f64, 1 certified f32 culling): the bounce-0 launch (coherent
+    // camera rays) and the others separately.  Both kinds of records give the reference's hits bit for bit, so the choice is a
+    // matter of speed only and it depends on the scene (axis-aligned scenes need the exact retake in most box decisions).  With
+    // ctx->hybrid = -1 a scene's first render that is big enough to time runs a few small PROBE passes on both kinds before its
+    // first frame (probe_trace_records) and the faster kind per launch kind is kept for the scene's lifetime in chosen_*; use_* is
+    // what the CURRENT call reads (counting frames and the f32 fast mode read f64 records whatever was chosen).
     int use_b0 = 0, use_rest = 0;
-    int tune_stage = 0;            // 0: nothing measured, 1: f64 measured, 2: both measured, choice made
-    double tune_ns[2][2] = {{0.0, 0.0}, {0.0, 0.0}};   // [variant][kind]: ns per ray of the bounce-0 launch / of the other launches
+    int chosen_b0 = -1, chosen_rest = -1;   // -1: not chosen yet
+    double tune_ms[2][2] = {{0.0, 0.0}, {0.0, 0.0}};   // [records][kind]: best time of the probe passes' bounce-0 launch / other traversal launches
+    double probe_ms = 0.0;         // wall time the probe passes took (once per scene)
 };
 
 namespace {
@@ -233,6 +236,10 @@ int reset_counters(cray_ctx* c) {
 // traversal grid.  Bit 30 of a child reference must be free for its helpers' bookkeeping: scenes beyond 2^27 leaf slots or
 // 2^30 nodes (and CRAY_TAIL_RAYS=0) run every mixed launch in the ordinary instantiation.
 int ensure_tail(cray_ctx* c, const cray_scene* s) {
+#ifndef CRAY_WITH_EXPERIMENTS
+    (void)s;
+    c->tail_rays = 0;   // the small-launch instantiation (DESIGN.md 3.1 TAIL: exact, tested, slower) is compiled with -DCRAY_WITH_EXPERIMENTS only
+#endif
     const bool want = c->tail_rays != 0 && c->steal && c->mix_trace && s->n_slots < (1u << 27) && s->dev.n_inner < (1u << 30);
     if (!want) {
         if (c->tail_res) { (void)hipFree(c->tail_res); c->tail_res = nullptr; }
@@ -323,6 +330,8 @@ void fill_stats(const Counters& h, cray_stats* st) {
                 100.0 * g[2] / g[0], g[2] ? (double)g[3] / g[2] : 0.0, g[4], g[4] ? (double)g[5] / g[4] : 0.0);
         fprintf(stderr, "diag %s: iterations with a lane at a leaf %.1f%%, at a sphere / disk slot %.1f%% (%.2f lanes), at a leaf of several slots %.1f%%\n",
                 a ? "any" : "closest", 100.0 * g[10] / g[0], 100.0 * g[11] / g[0], (double)g[13] / g[0], 100.0 * g[12] / g[0]);
+        fprintf(stderr, "diag %s (certified-f32 launches read these as): culling step in %.1f%% of the iterations with %.2f lanes/iter; exact step in %.1f%% with %.2f lanes/iter; %.2f lanes/iter waiting\n",
+                a ? "any" : "closest", 100.0 * g[10] / g[0], (double)g[7] / g[0], 100.0 * g[11] / g[0], (double)g[12] / g[0], (double)g[13] / g[0]);
         fprintf(stderr, "diag %s: pop loop entered in %.1f%% of the iterations, %.2f trips per entry (the wave runs the maximum over its lanes)\n",
                 a ? "any" : "closest", 100.0 * g[15] / g[0], g[15] ? (double)g[14] / g[15] : 0.0);
     }
@@ -381,8 +390,7 @@ extern "C" int cray_ctx_create(int device_id, void* stream, cray_ctx** out) {
         return v < lo ? lo : (v > hi ? hi : v);
     };
     c->mix_trace = env_int("CRAY_MIX_TRACE", 0, 1, c->mix_trace);
-    c->hybrid = env_int("CRAY_HYBRID", -1, 2, c->hybrid);
-    c->pair_pick = env_int("CRAY_PAIR_PICK", 0, 1, c->pair_pick);
+    c->hybrid = env_int("CRAY_HYBRID", -1, 1, c->hybrid);
     c->records_b0 = env_int("CRAY_RECORDS_B0", -1, 1, c->records_b0);
     c->records_rest = env_int("CRAY_RECORDS_REST", -1, 1, c->records_rest);
     c->log_queues = env_int("CRAY_LOG_QUEUES", 0, 1, 0);
@@ -396,6 +404,9 @@ extern "C" int cray_ctx_create(int device_id, void* stream, cray_ctx** out) {
     c->lds_shapes = (unsigned int)env_int("CRAY_LDS_SHAPES", 0, 1, (int)c->lds_shapes);
     c->tile_order = env_int("CRAY_TILE_ORDER", 0, 1, c->tile_order);
     c->leaf_min = (unsigned int)env_int("CRAY_LEAF_MIN", 0, 63, (int)c->leaf_min);
+    c->cull_min = (unsigned int)env_int("CRAY_CULL_MIN", 0, 63, (int)c->cull_min);
+    c->exact_min = (unsigned int)env_int("CRAY_EXACT_MIN", 0, 63, (int)c->exact_min);
+    c->tri_cull = (unsigned int)env_int("CRAY_TRI_CULL", 0, 1, (int)c->tri_cull);
     c->tail_rays = (unsigned int)env_int("CRAY_TAIL_RAYS", 0, (1 << 24) - 1, (int)c->tail_rays);
     c->tail_seg = (unsigned int)env_int("CRAY_TAIL_SEG", 0, 1, (int)c->tail_seg);
     c->tail_age = (unsigned int)env_int("CRAY_TAIL_AGE", 0, 255, (int)c->tail_age);
@@ -1046,53 +1057,69 @@ int ensure_inner32(cray_ctx* c, cray_scene* s) {
     s->dev.inner32 = i32;
     return CRAY_OK;
 }
-// Exact traversal with certified f32 culling: decided per scene (range of the bounds), records derived on first use.
+// Exact traversal with certified f32 culling: decided per scene (range of the bounds, size of the arena), records derived on first
+// use: ONE allocation, n_inner InnerNodeH followed by one LeafRecH per leaf slot (cray_device.h), references = byte offsets.
+size_t arena_bytes(const cray_ctx* c, const cray_scene* s) {
+    const uint64_t n_inner = s->dev.n_inner ? s->dev.n_inner : 1u, n_slots = (uint64_t)s->n_slots + 1u;   // + the zero pad slot of the f64 layout
+    const uint64_t leaves = (n_slots * (c->tri_cull ? kLeafCullStride + kLeafExactStride : kLeafExactPacked) + 127u) & ~(uint64_t)127u;
+    return (size_t)(n_inner * sizeof(InnerNodeH) + leaves + n_inner * sizeof(InnerNode));
+}
+bool hybrid_possible(const cray_ctx* c, const cray_scene* s) {
+    // a reference is a 32-bit offset; twice the offset of a C record must not wrap (x = 2 c + xk and back)
+    const uint64_t c_end = ((uint64_t)(s->dev.n_inner ? s->dev.n_inner : 1u) + (uint64_t)s->n_slots + 1u) * 64u;
+    return s->dev.bounds_in_div_range && hyb_scene_ok(s->dev.root_lo, s->dev.root_hi) && arena_bytes(c, s) < ((size_t)1 << 32) && (!c->tri_cull || c_end < (1ull << 31));
+}
 int ensure_hybrid(cray_ctx* c, cray_scene* s, int level) {
     if (level <= 0 || !s->hybrid_ok) return CRAY_OK;
-    const uint32_t n_inner = s->dev.n_inner ? s->dev.n_inner : 1u;
-    if (level == 2) {   // pair lines: a node's record + the record of one interior child in one 128-B line
-        if (s->dev.innerp) return CRAY_OK;
-        InnerNodeP* ip = nullptr;
-        HIP_TRY(hipMalloc((void**)&ip, (size_t)n_inner * sizeof(InnerNodeP)));
-        s->extra_allocs.push_back(ip);
-        hipLaunchKernelGGL(k_make_innerp, dim3((n_inner + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, s->dev.inner, n_inner, ip, (uint32_t)c->pair_pick);
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        HIP_TRY(hipGetLastError());
-        s->bytes += (size_t)n_inner * sizeof(InnerNodeP);
-        s->dev.innerp = ip;
-        return CRAY_OK;
-    }
     if (s->dev.innerh) return CRAY_OK;
-    InnerNodeH* ih = nullptr;
-    HIP_TRY(hipMalloc((void**)&ih, (size_t)n_inner * sizeof(InnerNodeH)));
-    s->extra_allocs.push_back(ih);
-    hipLaunchKernelGGL(k_make_innerh, dim3((n_inner + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, s->dev.inner, n_inner, ih);
+    const uint32_t n_inner = s->dev.n_inner ? s->dev.n_inner : 1u, n_slots = s->n_slots + 1u;
+    const size_t bytes = arena_bytes(c, s);
+    char* arena = nullptr;
+    HIP_TRY(hipMalloc((void**)&arena, bytes));
+    s->extra_allocs.push_back(arena);
+    const uint32_t c_base = n_inner * (uint32_t)sizeof(InnerNodeH);                                  // region C (or X when there is no culling)
+    const uint32_t x_base = c->tri_cull ? c_base + n_slots * kLeafCullStride : c_base;
+    const uint32_t x_stride = c->tri_cull ? kLeafExactStride : kLeafExactPacked;
+    const uint32_t leaf_stride = c->tri_cull ? kLeafCullStride : x_stride;
+    hipLaunchKernelGGL(k_make_innerh, dim3((n_inner + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, s->dev.inner, n_inner, reinterpret_cast<InnerNodeH*>(arena), c_base, leaf_stride);
+    if (c->tri_cull)
+        hipLaunchKernelGGL(k_make_leafh, dim3((n_slots + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, s->dev.slots, n_slots,
+                           reinterpret_cast<LeafCullH*>(arena + c_base), arena + x_base, x_stride);
+    else
+        HIP_TRY(hipMemcpyAsync(arena + x_base, s->dev.slots, (size_t)n_slots * sizeof(LeafSlot), hipMemcpyDeviceToDevice, c->stream));   // the slots as they are
+    const size_t r_base = bytes - (size_t)n_inner * sizeof(InnerNode);
+    HIP_TRY(hipMemcpyAsync(arena + r_base, s->dev.inner, (size_t)n_inner * sizeof(InnerNode), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipGetLastError());
-    s->bytes += (size_t)n_inner * sizeof(InnerNodeH);
-    s->dev.innerh = ih;
+    s->bytes += bytes;
+    s->dev.innerh = reinterpret_cast<const InnerNodeH*>(arena);
+    s->dev.arena_rbase = (uint32_t)r_base;
+    s->dev.root_ref_h = href_of(s->dev.root_ref, c_base, leaf_stride);
+    s->dev.arena_cull = c->tri_cull ? 1u : 0u;
+    s->dev.arena_xk = x_base - 2u * c_base;   // (mod 2^32: x = 2 c + xk holds in 32-bit arithmetic)
+    s->dev.arena_xstep = x_stride;
     return CRAY_OK;
 }
-// The records this call's traversal launches read.  Pinned by CRAY_HYBRID / ctx->hybrid >= 0; otherwise chosen per scene from
-// the first two frames that are big enough to time (cray_scene::use_b0).  `measuring` (out): this frame is one of those two.
-int choose_trace_records(cray_ctx* c, cray_scene* s, bool counting, size_t n_paths, int* measuring) {
-    *measuring = -1;
-    s->hybrid_ok = s->dev.bounds_in_div_range && hyb_scene_ok(s->dev.root_lo, s->dev.root_hi);
+// The records this call's traversal launches read.  Pinned by CRAY_HYBRID / ctx->hybrid >= 0 or CRAY_RECORDS_B0 / _REST; otherwise
+// the scene's choice (cray_scene::chosen_*).  `want_probe` (out): no choice exists yet and this call is big enough to make one —
+// the caller runs probe_trace_records before its first pass.  Never touches the choice itself.
+int choose_trace_records(cray_ctx* c, cray_scene* s, bool counting, size_t n_paths, bool* want_probe) {
+    if (want_probe) *want_probe = false;
+    s->hybrid_ok = hybrid_possible(c, s);
     if (!s->hybrid_ok) { s->use_b0 = s->use_rest = 0; return CRAY_OK; }
     if (c->hybrid >= 0) {
-        // the counting launches of a pair-line context run the plain f64 kernels (equal counters by construction)
-        s->use_b0 = s->use_rest = (c->hybrid == 2 && counting) ? 0 : c->hybrid;
-    } else if (c->records_b0 >= 0 && c->records_rest >= 0 && !counting) {
-        s->use_b0 = c->records_b0; s->use_rest = c->records_rest;   // pinned per launch kind (profiling passes: tools/profile_round.sh)
+        s->use_b0 = s->use_rest = c->hybrid;
     } else if (counting) {
         s->use_b0 = s->use_rest = 0;
-    } else if (s->tune_stage >= 2) {
-        // chosen
-    } else if (n_paths < ((size_t)1 << 21)) {
-        s->use_b0 = s->use_rest = 0;   // too small to tell anything: f64 records, nothing measured
+    } else if (c->records_b0 >= 0 && c->records_rest >= 0) {
+        s->use_b0 = c->records_b0; s->use_rest = c->records_rest;   // pinned per launch kind (profiling passes: tools/profile_round.sh)
+    } else if (s->chosen_b0 >= 0) {
+        s->use_b0 = s->chosen_b0; s->use_rest = s->chosen_rest;
+    } else if (n_paths < ((size_t)1 << 21) || !want_probe) {
+        s->use_b0 = s->use_rest = 0;   // too small to tell anything: f64 records, nothing chosen
     } else {
-        s->use_b0 = s->use_rest = s->tune_stage;   // frame 1 of the scene: f64 records; frame 2: certified f32 culling
-        *measuring = s->tune_stage;
+        s->use_b0 = s->use_rest = 1;   // both kinds of records are needed for the probe
+        *want_probe = true;
     }
     int e = ensure_hybrid(c, s, s->use_b0);
     if (!e) e = ensure_hybrid(c, s, s->use_rest);
@@ -1149,7 +1176,7 @@ struct ShadeLaunch<kNumShadeVariants> {
     static void go(int, int, bool, const cray_ctx*, size_t, hipStream_t, A...) {}
 };
 
-// The traversal launches: which records they read (v: 0 f64, 1 certified f32 culling, 2 pair lines) and whether the scene's few
+// The traversal launches: which records they read (v: 0 f64, 1 certified f32 culling) and whether the scene's few
 // sphere / disk records are staged in LDS (shp: those instantiations get bit 14 of refill_min) pick the instantiation.
 // Counting launches exist for v 0 and 1 only; the f64 any-hit launch keeps its LDS for the work sharing.
 template <bool ANY, bool COUNT, class... A>
@@ -1159,8 +1186,7 @@ void launch_trace(int v, bool shp, int grid, hipStream_t st, A... a) {
         if (v == 1) hipLaunchKernelGGL((k_trace<ANY, true, 1>), g, b, 0, st, a...);
         else hipLaunchKernelGGL((k_trace<ANY, true, 0>), g, b, 0, st, a...);
     } else {
-        if (v == 2) hipLaunchKernelGGL((k_trace<ANY, false, 2>), g, b, 0, st, a...);
-        else if (v == 1 && shp) hipLaunchKernelGGL((k_trace<ANY, false, 1, true>), g, b, 0, st, a...);
+        if (v == 1 && shp) hipLaunchKernelGGL((k_trace<ANY, false, 1, true>), g, b, 0, st, a...);
         else if (v == 1) hipLaunchKernelGGL((k_trace<ANY, false, 1>), g, b, 0, st, a...);
         else if (shp && !ANY) hipLaunchKernelGGL((k_trace<false, false, 0, true>), g, b, 0, st, a...);
         else hipLaunchKernelGGL((k_trace<ANY, false, 0>), g, b, 0, st, a...);
@@ -1171,12 +1197,15 @@ void launch_mixed(int v, bool shp, bool tail, int grid, hipStream_t st, A... a) 
     const dim3 g(grid), b(kBlock);
     // a mixed launch is launched twice when the small-launch instantiation is on (Counters::tail_rays != 0): each of the two
     // returns at once unless the launch has its size — the host does not know the queue lengths
+#ifdef CRAY_WITH_EXPERIMENTS
     if (tail) {
         if (shp) hipLaunchKernelGGL((k_trace_mixed<0, true, true>), g, b, 0, st, a...);
         else hipLaunchKernelGGL((k_trace_mixed<0, false, true>), g, b, 0, st, a...);
     }
-    if (v == 2) hipLaunchKernelGGL(k_trace_mixed<2>, g, b, 0, st, a...);
-    else if (v == 1 && shp) hipLaunchKernelGGL((k_trace_mixed<1, true>), g, b, 0, st, a...);
+#else
+    (void)tail;
+#endif
+    if (v == 1 && shp) hipLaunchKernelGGL((k_trace_mixed<1, true>), g, b, 0, st, a...);
     else if (v == 1) hipLaunchKernelGGL(k_trace_mixed<1>, g, b, 0, st, a...);
     else if (shp) hipLaunchKernelGGL((k_trace_mixed<0, true>), g, b, 0, st, a...);
     else hipLaunchKernelGGL(k_trace_mixed<0>, g, b, 0, st, a...);
@@ -1246,7 +1275,8 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
                                          (const uint32_t*)q_next, (const unsigned int*)n_next, ctr, &ctr->trace_head, c->refill_min, 0u);
             else launch_mixed(s->use_rest, shp, c->tail_res != nullptr, g_trace, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, (const uint32_t*)q_next,
                               (const unsigned int*)n_next, ctr, &ctr->trace_head,
-                              (s->use_rest ? c->refill_min_hyb | (c->refill_min_any_hyb << 16) : c->refill_min | (c->refill_min_any << 16)) | (c->leaf_min << 7) | (c->steal ? 0x8000u : 0u) | shp_bit);
+                              (s->use_rest ? c->refill_min_hyb | (c->refill_min_any_hyb << 16) | ((s->dev.arena_cull ? c->cull_min : c->leaf_min) << 7) | (c->exact_min << 23)
+                                           : c->refill_min | (c->refill_min_any << 16) | (c->leaf_min << 7)) | (c->steal ? 0x8000u : 0u) | shp_bit);
             if (tm) { int e = tm->end(); if (e) return e; }
         } else {
             if (tm) { int e = tm->begin(FAM_ANY); if (e) return e; }
@@ -1431,6 +1461,72 @@ int ensure_tile_order(cray_ctx* c, cray_scene* s, const cray_render_params& prm,
     return CRAY_OK;
 }
 
+// Which records are faster for THIS scene, measured before its first frame (round 5; rounds 4 timed a scene's first two frames, so a
+// host that renders one frame per process — the reference's own usage, craytracer.rs:336-372 — never got the faster records).
+// A probe pass is an ordinary pass over a sample of the rank's pixels (every k-th of its list, 2 Mi paths) whose film is thrown
+// away: the launch sequence, the queues and the path pool are the frame's own.  f32 culling first (unmeasured: first launches of the
+// instantiations, cold caches), then f64 / f32 / f64 / f32, the best time per kind of records and launch kind counts; the f32
+// culling has to win by more than 1 % to replace the plain records.  ~3 % of one configs[2] frame, once per scene.
+// Ranks probe their own pixels: their choices may differ, their films cannot (both kinds of records are exact).
+__global__ void __launch_bounds__(kBlock) k_stride_list(const uint32_t* __restrict__ in, uint32_t n_out, uint32_t stride, uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n_out) out[i] = in[(size_t)i * stride];
+}
+int probe_trace_records(cray_ctx* c, cray_scene* s, const cray_render_params& prm, uint32_t n_pix_rank, uint32_t s_begin, uint32_t s_end) {
+    const auto t0 = std::chrono::steady_clock::now();
+    uint32_t spp = s_end - s_begin;
+    if (spp > prm.sample_batch && prm.sample_batch) spp = prm.sample_batch;
+    size_t want_paths = (size_t)1 << 21;
+    if (want_paths > c->capacity) want_paths = c->capacity;
+    uint32_t n_pix = (uint32_t)(want_paths / spp);
+    if (n_pix > n_pix_rank) n_pix = n_pix_rank;
+    if (n_pix == 0) { s->use_b0 = s->use_rest = 0; return CRAY_OK; }
+    const uint32_t stride = n_pix_rank / n_pix;
+    DevMem mem;
+    uint32_t* d_list;
+    HIP_TRY(mem.get(&d_list, n_pix));
+    hipLaunchKernelGGL(k_stride_list, dim3((n_pix + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->pix_order, n_pix, stride, d_list);
+    const uint32_t* const frame_order = c->pix_order;
+    c->pix_order = d_list;
+    const PassPlan pp{0u, n_pix, s_begin, s_begin + spp};
+    double best[2][2] = {{1e300, 1e300}, {1e300, 1e300}};
+    bool overflow = false;
+    int e = CRAY_OK;
+    static const int order[5] = {1, 0, 1, 0, 1};
+    for (int k = 0; k < 5 && !e && !overflow; k++) {
+        const int v = order[k];
+        s->use_b0 = s->use_rest = v;
+        if ((e = reset_counters(c))) break;
+        EventTimer timer(c);
+        if ((e = run_pass(c, s, prm, pp, &timer))) break;
+        Counters h;
+        if (hipMemcpyAsync(&h, c->counters, sizeof(h), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+            set_last_error("probe pass failed: %s", hipGetErrorString(hipGetLastError()));
+            e = CRAY_ERR_HIP;
+            break;
+        }
+        double ms[FAM_COUNT]; uint32_t launches[FAM_COUNT];
+        if ((e = timer.collect(ms, launches))) break;
+        overflow = h.stack_overflow != 0;   // (the frame itself will report it and come back with the deeper stack: choose then)
+        if (k == 0) continue;
+        const double t_b0 = ms[FAM_CLOSEST], t_rest = ms[FAM_MIXED] + ms[FAM_ANY];
+        if (t_b0 < best[v][0]) best[v][0] = t_b0;
+        if (t_rest < best[v][1]) best[v][1] = t_rest;
+    }
+    c->pix_order = frame_order;
+    if (e) return e;
+    if (overflow) { s->use_b0 = s->use_rest = 0; return CRAY_OK; }
+    for (int v = 0; v < 2; v++) for (int k = 0; k < 2; k++) s->tune_ms[v][k] = best[v][k];
+    s->chosen_b0 = best[1][0] < 0.99 * best[0][0] ? 1 : 0;
+    s->chosen_rest = (best[0][1] > 0.0 && best[1][1] < 0.99 * best[0][1]) ? 1 : 0;
+    s->use_b0 = s->chosen_b0; s->use_rest = s->chosen_rest;
+    s->probe_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (c->log_queues)
+        fprintf(stderr, "[cray] traversal records chosen for this scene from %u probe pixels x %u samples in %.1f ms: bounce 0 %s (%.3f vs %.3f ms), other launches %s (%.3f vs %.3f ms)\n",
+                n_pix, spp, s->probe_ms, s->chosen_b0 ? "f32 culling" : "f64", best[1][0], best[0][0], s->chosen_rest ? "f32 culling" : "f64", best[1][1], best[0][1]);
+    return CRAY_OK;
+}
+
 // Every pass of this rank's share of the frame, accumulated into c->film (sums over samples, not yet divided by
 // num_samples); fills everything of `stats` but `seconds`.  Local to the rank: no collective in here, so a rank that
 // has to repeat its frame with the deep traversal stack does not disturb the others.
@@ -1444,10 +1540,9 @@ int render_local(cray_ctx* c, cray_scene* s, const cray_render_params* prm, cray
     if ((e = ensure_pix_list(c, W, H, *prm))) return e;
     if (prm->precision == CRAY_PRECISION_F32_TRAVERSAL && (e = ensure_fast_layout(c, s))) return e;
     const size_t n_pix_rank = c->pix_count;
-    int measuring = -1;   // >= 0: this frame's traversal times decide which records the scene's later frames read
+    bool want_probe = false;   // no records chosen for this scene yet, and this frame is big enough to choose them
     if ((e = choose_trace_records(c, s, prm->count_traversal != 0 || prm->precision != CRAY_PRECISION_F64,
-                                  n_pix_rank * (size_t)(s_end > s_begin ? s_end - s_begin : 0), &measuring))) return e;
-    const uint32_t used_records = (uint32_t)(s->use_b0 | (s->use_rest << 4));   // what THIS call's launches read (cray_stats.trace_records)
+                                  n_pix_rank * (size_t)(s_end > s_begin ? s_end - s_begin : 0), &want_probe))) return e;
     if ((e = ensure_tail(c, s))) return e;
     if ((e = ensure_tile_order(c, s, *prm, n_pix_rank * (size_t)(s_end > s_begin ? s_end - s_begin : 0)))) return e;
     const size_t film_floats = (size_t)W * H * 3;
@@ -1478,12 +1573,14 @@ int render_local(cray_ctx* c, cray_scene* s, const cray_render_params* prm, cray
         capacity /= 2;
     }
     const std::vector<PassPlan> passes = plan(c->capacity, (uint32_t)n_pix_rank, s_begin, s_end, prm->sample_batch);
+    if (want_probe && (e = probe_trace_records(c, s, *prm, (uint32_t)n_pix_rank, s_begin, s_end))) return e;
+    const uint32_t used_records = (uint32_t)(s->use_b0 | (s->use_rest << 4));   // what THIS call's launches read (cray_stats.trace_records)
 
     for (int attempt = 0;; attempt++) {
         HIP_TRY(hipMemsetAsync(c->film, 0, film_floats * sizeof(float), c->stream));
         if ((e = reset_counters(c))) return e;
         EventTimer timer(c);
-        EventTimer* tm = (stats || measuring >= 0) ? &timer : nullptr;
+        EventTimer* tm = stats ? &timer : nullptr;
         for (const PassPlan& pp : passes)
             if ((e = run_pass(c, s, *prm, pp, tm))) return e;
         Counters h;
@@ -1492,21 +1589,6 @@ int render_local(cray_ctx* c, cray_scene* s, const cray_render_params* prm, cray
         if (err != hipSuccess) { set_last_error("render failed: %s", hipGetErrorString(err)); return CRAY_ERR_HIP; }
         double ms[FAM_COUNT]; uint32_t launches[FAM_COUNT];
         if (tm && (e = timer.collect(ms, launches))) return e;
-        if (measuring >= 0 && !h.stack_overflow) {
-            // ns per ray of the bounce-0 launch (one camera ray per path) and of all the other traversal launches
-            const double r0 = (double)need, r1 = (double)(h.closest_rays + h.shadow_rays) - (double)h.shadow_skipped - r0;
-            s->tune_ns[measuring][0] = ms[FAM_CLOSEST] * 1e6 / (r0 > 0 ? r0 : 1.0);
-            s->tune_ns[measuring][1] = (ms[FAM_MIXED] + ms[FAM_ANY]) * 1e6 / (r1 > 0 ? r1 : 1.0);
-            s->tune_stage = measuring + 1;
-            if (s->tune_stage == 2) {
-                // the f32 culling has to win by more than the noise of one frame (1 %) to replace the plain records
-                s->use_b0 = s->tune_ns[1][0] < 0.99 * s->tune_ns[0][0] ? 1 : 0;
-                s->use_rest = (r1 > 0 && s->tune_ns[1][1] < 0.99 * s->tune_ns[0][1]) ? 1 : 0;
-                if (c->log_queues)
-                    fprintf(stderr, "[cray] traversal records chosen for this scene: bounce 0 %s (%.3f vs %.3f ns/ray), other launches %s (%.3f vs %.3f ns/ray)\n",
-                            s->use_b0 ? "f32 culling" : "f64", s->tune_ns[1][0], s->tune_ns[0][0], s->use_rest ? "f32 culling" : "f64", s->tune_ns[1][1], s->tune_ns[0][1]);
-            }
-        }
         if (stats) {
             memset(stats, 0, sizeof(*stats));
             fill_stats(h, stats);
@@ -1659,7 +1741,7 @@ extern "C" int cray_trace(cray_ctx* c, cray_scene* s, const cray_ray* rays, size
     const int g = grid_for(c, n, 8);
     Counters* ctr = c->counters;
     // the per-ray hook reads the records the context is pinned to (CRAY_HYBRID); a context that chooses per scene reads f64 here
-    s->hybrid_ok = s->dev.bounds_in_div_range && hyb_scene_ok(s->dev.root_lo, s->dev.root_hi);
+    s->hybrid_ok = hybrid_possible(c, s);
     const int level = (c->hybrid > 0 && s->hybrid_ok) ? c->hybrid : 0;
     if ((e = ensure_hybrid(c, s, level))) return e;
     const bool shp = shapes_fit_lds(c, s->dev);   // the timed instantiations the frame loop would launch for this scene
@@ -2240,7 +2322,7 @@ extern "C" int cray_scene_broadcast(cray_ctx* c, cray_scene* mine, int root, cra
         s->ctx = c; s->dev = h.dev; s->n_prims = h.n_prims;
         s->features = h.features; s->shade_variant = h.shade_variant;
         s->n_slots = h.n_slots;
-        s->dev.inner32 = nullptr; s->dev.slots32 = nullptr; s->dev.innerh = nullptr; s->dev.innerp = nullptr;   // the fast-mode records are derived per rank on first use
+        s->dev.inner32 = nullptr; s->dev.slots32 = nullptr; s->dev.innerh = nullptr;   // the fast-mode records are derived per rank on first use
         const void** fields[kSceneArrays];
         scene_arrays(s->dev, fields);
         for (int i = 0; i < kSceneArrays && !bad; i++) {

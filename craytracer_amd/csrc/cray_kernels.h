@@ -59,9 +59,9 @@ constexpr uint32_t kTraceLdsShapes = 8;   // sphere + disk records (272 B each) 
 #else
 #define CRAY_CHILD_KEY child_key_code
 #endif
-//  HYB        : certified f32 culling (cray_math.h hyb_key): interior nodes are read as 64-B f32 records, every decision the f32
-//               enclosure cannot certify is retaken from the f64 record in a RESOLVE step of the lane.  Same hits, same counters.
-//  HYB = 2    : the same with pair lines (InnerNodeP): the record of the child a lane descends into may already be in its registers.
+//  HYB        : certified f32 culling (cray_math.h hyb_pair, tri_cull32): interior nodes are read as 64-B f32 records and leaf slots
+//               as f32 copies of their triangles; every decision the f32 enclosure cannot certify is retaken from the f64 record in
+//               a RESOLVE / EXACT step of the lane (cray_trace_step_hyb.inc).  Same hits, same counters.
 //  SHAPES_LDS : the scene's few sphere / disk records are staged in LDS by every block (the host picks this instantiation when they fit).
 //  TAIL       : the instantiation for SMALL mixed launches (fewer than Counters::tail_rays rays): such a launch is all drain — every
 //               lane holds one or two rays from the start and the launch lasts as long as its longest ray — so here idle lanes
@@ -116,6 +116,11 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PsArg ps_ar
     // mostly closest-hit rays once a launch is small (profiles/r04_experiments.md).  The opt-in small-launch instantiation
     // (TAIL, below) has it as well, together with the certified split of closest-hit rays.
     static_assert(!TAIL || (MODE == kTraceMixed && !COUNT && HYB == 0), "the small-launch instantiation reads f64 records");
+    static_assert(HYB == 0 || HYB == 1, "records: 0 f64, 1 certified f32 culling");
+#ifndef CRAY_CULL_HITS
+#define CRAY_CULL_HITS 1   // any-hit lanes end at a triangle whose f32 copy certifies the HIT (no distance is needed); 0: A/B builds
+#endif
+    constexpr bool kCullHits = MODE != kTraceClosest && CRAY_CULL_HITS != 0;
     constexpr bool STEAL = !COUNT && !HYB && (MODE == kTraceAny || TAIL);
     const bool steal_on = STEAL && (refill_min & 0x8000u) != 0;
     unsigned int age = 0, age_min = 0;   // TAIL: iterations this lane's segment has been walked / before it may hand parts out
@@ -228,18 +233,15 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PsArg ps_ar
     float t_lo = 0.f, t_hi = 0.f;
     uint32_t res = 0;
     bool resolve = false;
-    bool have = false;   // HYB 2: the record of `cur` came with its parent's line and sits in c0..c3
-    // HYB 2: the second half of the pair line a lane fetched last (the companion child's record); kept across iterations
-    double2 c0 = make_double2(0.0, 0.0), c1 = c0, c2 = c0, c3 = c0;
+    bool lexact = false;     // HYB: the slot `cur` names was not decided by its f32 copy — its f64 triangle is tested next
+    float d32x = 0.f, d32y = 0.f, d32z = 1.f;   // HYB: RN32 of ray.d (tri_cull32)
 
     if constexpr (HYB != 0) {
         // (how the loop is spelled: see the head of cray_trace_step.inc)
         auto step = [&]() __attribute__((always_inline)) -> bool {
-#define CRAY_STEP_DRAIN false
 #define CRAY_STEP_BREAK return true
 #define CRAY_STEP_CONTINUE return false
-#include "cray_trace_step.inc"
-#undef CRAY_STEP_DRAIN
+#include "cray_trace_step_hyb.inc"
 #undef CRAY_STEP_BREAK
 #undef CRAY_STEP_CONTINUE
             return false;
@@ -537,7 +539,14 @@ __global__ void __launch_bounds__(kBlock) k_make_inner32(const InnerNode* __rest
     o.ref0 = a.ref0; o.ref1 = a.ref1; o.axis = a.axis; o.pad_ = 0;
     out[i] = o;
 }
-__global__ void __launch_bounds__(kBlock) k_make_innerh(const InnerNode* __restrict__ in, uint32_t n, InnerNodeH* __restrict__ out) {
+// The arena of the certified f32 culling (cray_device.h): InnerNodeH records with references in the arena's encoding, then the
+// leaf slots' C and / or X records.  Derived on the device from the f64 layout.
+// (leaf_base / leaf_stride: where the records a leaf reference names start, and their stride)
+__host__ __device__ __forceinline__ uint32_t href_of(uint32_t ref, uint32_t leaf_base, uint32_t leaf_stride) {
+    if (!ref_is_leaf(ref)) return ref * (uint32_t)sizeof(InnerNodeH);
+    return (leaf_base + ref_leaf_first(ref) * leaf_stride) | kHLeaf | (ref_leaf_count(ref) - 1u);
+}
+__global__ void __launch_bounds__(kBlock) k_make_innerh(const InnerNode* __restrict__ in, uint32_t n, InnerNodeH* __restrict__ out, uint32_t leaf_base, uint32_t leaf_stride) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const InnerNode a = in[i];
@@ -546,37 +555,26 @@ __global__ void __launch_bounds__(kBlock) k_make_innerh(const InnerNode* __restr
         o.lo[k][0] = f32_down(a.lo0[k]); o.hi[k][0] = f32_up(a.hi0[k]);
         o.lo[k][1] = f32_down(a.lo1[k]); o.hi[k][1] = f32_up(a.hi1[k]);
     }
-    o.ref0 = a.ref0; o.ref1 = a.ref1; o.axis = a.axis; o.pad_ = 0;
+    o.ref0 = href_of(a.ref0, leaf_base, leaf_stride); o.ref1 = href_of(a.ref1, leaf_base, leaf_stride); o.axis = a.axis; o.pad_ = 0;
     out[i] = o;
 }
-// pair lines: a node's certified-f32 record followed by the record of one interior child.  pick 0: the left child when it is
-// interior, else the right one; pick 1: the interior child with the larger surface area (the more likely descent).
-__device__ __forceinline__ InnerNodeH make_h(const InnerNode& a) {
-    InnerNodeH o;
-    for (int k = 0; k < 3; k++) {
-        o.lo[k][0] = f32_down(a.lo0[k]); o.hi[k][0] = f32_up(a.hi0[k]);
-        o.lo[k][1] = f32_down(a.lo1[k]); o.hi[k][1] = f32_up(a.hi1[k]);
-    }
-    o.ref0 = a.ref0; o.ref1 = a.ref1; o.axis = a.axis; o.pad_ = 0;
-    return o;
-}
-__global__ void __launch_bounds__(kBlock) k_make_innerp(const InnerNode* __restrict__ in, uint32_t n, InnerNodeP* __restrict__ out, uint32_t pick) {
+// (cull: the C region, or nullptr; exact / x_stride: the X region and its stride in bytes)
+__global__ void __launch_bounds__(kBlock) k_make_leafh(const LeafSlot* __restrict__ in, uint32_t n, LeafCullH* __restrict__ cull, char* __restrict__ exact, uint32_t x_stride) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    const InnerNode a = in[i];
-    InnerNodeP o;
-    o.self = make_h(a);
-    const bool in0 = !ref_is_leaf(a.ref0), in1 = !ref_is_leaf(a.ref1);
-    uint32_t code = in0 ? 1u : (in1 ? 2u : 0u);
-    if (pick == 1u && in0 && in1) {
-        const double x0 = a.hi0[0] - a.lo0[0], y0 = a.hi0[1] - a.lo0[1], z0 = a.hi0[2] - a.lo0[2];
-        const double x1 = a.hi1[0] - a.lo1[0], y1 = a.hi1[1] - a.lo1[1], z1 = a.hi1[2] - a.lo1[2];
-        code = (x1 * y1 + y1 * z1 + z1 * x1) > (x0 * y0 + y0 * z0 + z0 * x0) ? 2u : 1u;
+    const LeafSlot a = in[i];
+    LeafExactH x;
+    for (int k = 0; k < 3; k++) { x.e1[k] = a.e1[k]; x.e2[k] = a.e2[k]; x.v0[k] = a.v0[k]; }
+    x.prim = a.prim; x.kind = a.kind;
+    *reinterpret_cast<LeafExactH*>(exact + (size_t)i * x_stride) = x;
+    if (cull) {
+        LeafCullH o;
+        for (int k = 0; k < 3; k++) { o.v0[k] = a.v0[k]; o.e1f[k] = (float)a.e1[k]; o.e2f[k] = (float)a.e2[k]; }
+        o.prim = a.prim; o.kind = a.kind;
+        o.e1m = f32_up(fmax(fmax(fabs(a.e1[0]), fabs(a.e1[1])), fabs(a.e1[2])));
+        o.e2m = f32_up(fmax(fmax(fabs(a.e2[0]), fabs(a.e2[1])), fabs(a.e2[2])));
+        cull[i] = o;
     }
-    o.self.pad_ = code;
-    if (code) o.comp = make_h(in[code == 1u ? a.ref0 : a.ref1]);
-    else { InnerNodeH z; __builtin_memset(&z, 0, sizeof(z)); o.comp = z; }
-    out[i] = o;
 }
 __global__ void __launch_bounds__(kBlock) k_make_slots32(const LeafSlot* __restrict__ in, uint32_t n, LeafSlot32* __restrict__ out) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;

@@ -425,6 +425,104 @@ CRAY_HD HybPair hyb_pair(hyb_f2 lox, hyb_f2 loy, hyb_f2 loz, hyb_f2 hix, hyb_f2 
     return out;
 }
 
+// ---------------------------------------------------------------------------------
+// Certified f32 culling of the TRIANGLE test (round 5) — the leaf analogue of hyb_pair.
+//
+// Shape::Triangle::intersect (shape.rs:216-262) answers `false` for four out of five triangles a ray is tested against, and the
+// exact f64 test costs ~90 instructions, three of them divisions.  The numerators of Moller-Trumbore decide that answer without
+// any division:  with s = sign(den),
+//     u < 0  <=>  nu s < 0      u > 1  <=>  nu s > |den|      v < 0  <=>  nv s < 0      u + v > 1  <=>  (nu + nv) s > |den|
+//     t <= 0 <=>  nt s <= 0     t >= tmax  <=>  nt s >= tmax |den|
+// tri_cull32 evaluates den, nu, nv, nt in f32 from f32 copies of d, e1, e2 and from T = RN32(RN64(o - v0)) — the subtraction in
+// f64 from the f64 vertex, so that T carries a RELATIVE error only, however close the origin is to the triangle — together with
+// a rigorous bound of their distance from the f64 values the reference computes, and says MISS only when one of the six
+// conditions holds for every value inside the bounds.  Everything else (hits, near-edge cases, degenerate triangles, rays outside
+// the certified range) is `unknown` and takes the exact f64 test.  What is certified is the reference's ANSWER ("returns false"),
+// not each comparison: a condition that holds for the real quotients makes the reference return false at that comparison or at
+// an earlier one.
+//
+// Bound (u = 2^-24; * = real arithmetic on the f64 inputs; Dm, E1m, E2m, Tm = max-norms of d, e1, e2, T):
+//   inputs        d32, e1_32, e2_32: relative error u;  T32: u(1 + 2^-29)
+//   P32 = fl(fma(d_a, e2_b, -fl(d_b e2_a)))    |P32_i - P*_i| <= 2u|d_a e2_b| + 3u|d_b e2_a| + u|P32_i| <= 7.01u Dm E2m,  |P*_i| <= 2 Dm E2m
+//   a term P32_i x32_i of a dot product           |P32_i x32_i - P*_i x_i| <= 7.01u Dm E2m Xm (1 + u) + 2 Dm E2m u Xm = 9.02u Dm E2m Xm
+//   three terms + three roundings of partial sums (each <= 6.01 Dm E2m Xm)      27.06u + 18.03u = 45.1u Dm E2m Xm
+// and the same with (T, e1) in place of (d, e2) for Q = T x e1.  Hence, with K = 47u (4 % spare: the f32 evaluation of the bounds
+// themselves, the max-norms taken from rounded values, second-order terms, and the f64 roundings of the reference, ~60 x 2^-53):
+//   |den32 - den64| <= K Dm E1m E2m     |nu32 - nu64| <= K Dm E2m Tm     |nv32 - nv64| <= K Dm E1m Tm     |nt32 - nt64| <= K E1m E2m Tm
+// each plus 2^-100 for f32 underflow (the caller guarantees |coordinates| <= 2^40 and 2^-30 <= |d_i| <= 2^30: nothing overflows).
+// Quotients: u64 = RN(nu64 / den64) > 1 needs nu64 s > |den64| (1 + 2^-52); the comparisons below leave a relative 8u (kCullRel)
+// on the larger side, which also covers their own f32 roundings.  t_hi >= ray.tmax comes from hyb_tmax (+inf for a tmax f32
+// cannot bracket: then `t >= tmax` is never certified).
+// tests/test_tri_cull.py: a certified answer never contradicts the literal f64 test (host build of this function).
+// ---------------------------------------------------------------------------------
+#ifndef CRAY_CULL_K_UNITS
+#define CRAY_CULL_K_UNITS 47.0f
+#endif
+constexpr float kCullK = CRAY_CULL_K_UNITS * 0x1p-24f;   // (the macro exists for the mutation check of tests/test_tri_cull.py)
+constexpr float kCullFloor = 0x1p-100f;
+constexpr float kCullRel = 1.0f + 0x1p-21f;
+enum { kCullUnknown = 0, kCullMiss = 1, kCullHit = 2 };
+struct TriCull {
+    bool miss;   // the reference's test certainly returns false
+    bool hit;    // (WANT_HIT only) it certainly returns true: every comparison certainly passes
+};
+CRAY_HD float cull_flip(float x, uint32_t sign_bit) {
+    uint32_t b;
+    __builtin_memcpy(&b, &x, 4);
+    b ^= sign_bit;
+    float r;
+    __builtin_memcpy(&r, &b, 4);
+    return r;
+}
+// e1m / e2m: max |e1_i| / max |e2_i| of the f64 edges, rounded UP to f32.  ray_ok: the ray is inside the certified range (hyb_ray).
+template <bool WANT_HIT>
+CRAY_HD TriCull tri_cull32(double v0x, double v0y, double v0z, float e1x, float e1y, float e1z, float e2x, float e2y, float e2z, float e1m, float e2m,
+                           double ox, double oy, double oz, float dx, float dy, float dz, float t_lo, float t_hi, bool ray_ok) {
+    const float Tx = (float)(ox - v0x), Ty = (float)(oy - v0y), Tz = (float)(oz - v0z);
+    const float Px = fmaf(dy, e2z, -(dz * e2y)), Py = fmaf(dz, e2x, -(dx * e2z)), Pz = fmaf(dx, e2y, -(dy * e2x));
+    const float den = fmaf(Pz, e1z, fmaf(Py, e1y, Px * e1x));
+    const float nu = fmaf(Pz, Tz, fmaf(Py, Ty, Px * Tx));
+    const float Qx = fmaf(Ty, e1z, -(Tz * e1y)), Qy = fmaf(Tz, e1x, -(Tx * e1z)), Qz = fmaf(Tx, e1y, -(Ty * e1x));
+    const float nv = fmaf(Qz, dz, fmaf(Qy, dy, Qx * dx));
+    const float nt = fmaf(Qz, e2z, fmaf(Qy, e2y, Qx * e2x));
+    // the four bounds
+    const float x = kCullK * fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
+    const float y = e1m * e2m;
+    const float c = fmaxf(fmaxf(fabsf(Tx), fabsf(Ty)), fabsf(Tz));
+    const float xc = x * c;
+    const float e_den = fmaf(x, y, kCullFloor), e_nu = fmaf(xc, e2m, kCullFloor), e_nv = fmaf(xc, e1m, kCullFloor), e_nt = fmaf(kCullK * c, y, kCullFloor);
+    // numerators with the sign of den folded in; bounds of |den|
+    uint32_t sb;
+    __builtin_memcpy(&sb, &den, 4);
+    sb &= 0x80000000u;
+    const float aden = fabsf(den), nus = cull_flip(nu, sb), nvs = cull_flip(nv, sb), nts = cull_flip(nt, sb);
+    const bool den_ok = aden > e_den;   // the sign of den64 is the sign of den32 (false for NaN bounds)
+    const float d_hi = aden + e_den;
+    const float nlu = nus - e_nu, nlv = nvs - e_nv, nlt = nts - e_nt;   // lower ends
+    bool miss = nus < -e_nu;                                        // u < 0
+    miss = miss || fmaf(-kCullRel, d_hi, nlu) > 0.0f;              // u > 1
+    miss = miss || nvs < -e_nv;                                     // v < 0
+    miss = miss || fmaf(-kCullRel, d_hi, nlu + nlv) > 0.0f;        // u + v > 1
+    miss = miss || nts < -e_nt;                                     // t < 0 (<= EPSILON)
+    miss = miss || fmaf(-kCullRel, t_hi * d_hi, nlt) > 0.0f;       // t >= ray.tmax
+    TriCull out;
+    out.miss = miss && den_ok && ray_ok;
+    out.hit = false;
+    if (WANT_HIT) {
+        // every comparison of the reference certainly passes: |den| >= EPSILON, 0 <= u, 0 <= v, u + v <= 1 (hence u <= 1),
+        // EPSILON < t < ray.tmax.  (t_lo <= ray.tmax; kHybEpsUp = 1.1e-9 leaves 10 % on EPSILON)
+        const float d_lo = aden - e_den;
+        const float nhu = nus + e_nu, nhv = nvs + e_nv, nht = nts + e_nt;   // upper ends
+        bool hit = d_lo >= kHybEpsUp;
+        hit = hit && nlu >= 0.0f && nlv >= 0.0f;
+        hit = hit && fmaf(-kCullRel, nhu + nhv, d_lo) > 0.0f;
+        hit = hit && nlt > kHybEpsUp * d_hi;
+        hit = hit && fmaf(-kCullRel, nht, t_lo * d_lo) > 0.0f;
+        out.hit = hit && ray_ok;
+    }
+    return out;
+}
+
 }  // namespace cray
 
 // -----------------------------------------------------------------------------------------

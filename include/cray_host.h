@@ -70,6 +70,11 @@ uint64_t cray_host_div_fast_mismatches(const double* a, const double* d, uint64_
 uint64_t cray_host_child_key_mismatches(const double* lo, const double* hi, const double* o, const double* d, uint64_t n,
                                         uint64_t* n_checked);
 
+/* Certified f32 culling of the triangle test (cray_math.h tri_cull32) against the literal f64 Moller-Trumbore
+ * (reference: src/shape.rs:216-262) on n triangles (v0, e1, e2), rays (o, d) and ray.tmax values: returns the number of certified
+ * answers that contradict the exact test.  counts[4] (optional): unknown, certified misses, certified hits, rays outside the range. */
+uint64_t cray_host_tri_cull_violations(const double* v0, const double* e1, const double* e2, const double* o, const double* d, const double* tmax,
+                                       uint64_t n, uint64_t* counts);
 /* Certified f32 culling (cray_math.h hyb_key / hyb_status) against the literal slab test on n boxes, rays and
  * ray.tmax values: returns how many times the f32 side certified a decision (visit: key < tmax, cull: key >= tmax) that the
  * exact f64 key contradicts — must be 0.  counts[4] = decisions left to the exact path, certified visits, certified culls,

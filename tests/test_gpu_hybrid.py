@@ -1,9 +1,6 @@
-"""The opt-in certified f32 culling of the exact traversal (CRAY_HYBRID=1): 64-B f32 node records decide what
-they can certify, everything else is retaken from the f64 record.  It must change nothing: hits, distances and the node /
-primitive counters against the oracle, films bit for bit against the default (f64 records) context.
-CRAY_HYBRID=2 (round 4) is the same with pair lines — a node's record and the record of one interior child in one 128-B line,
-the child's record carried in registers when the lane descends into it: timed kernels only (the counting launches of such a
-context run the plain f64 kernels), so its any-hit answers, hit records and films are what is checked here."""
+"""The certified f32 culling of the exact traversal (CRAY_HYBRID=1): 64-B f32 node records and f32 copies of the
+triangles decide what they can certify, everything else is retaken from the f64 records.  It must change nothing: hits,
+distances and the node / primitive counters against the oracle, films bit for bit against the f64-records context."""
 import numpy as np
 import pytest
 
@@ -14,7 +11,7 @@ from tests.parity_util import small_scenes, random_rays
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope='module', params=['1', '2'])
+@pytest.fixture(scope='module', params=['1'])
 def ctxs(request):
     import os
     old = os.environ.get('CRAY_HYBRID')
@@ -88,36 +85,73 @@ def test_hybrid_film_is_the_default_film(ctxs, name):
     dh.close(); dr.close()
 
 
-def test_a_context_that_chooses_its_records_per_scene_renders_the_same_film():
-    """Default contexts (CRAY_HYBRID unset) time a scene's first frame on f64 records and its second on certified f32 culling and
-    keep, per launch kind, whichever was faster (cray_stats.trace_records says which records a call read).  The choice must never
-    show in the film: all three frames equal the oracle's, bit for bit.  Frames too small to time stay on f64 records."""
+def _default_context():
     import os
-    old = os.environ.pop('CRAY_HYBRID', None)
+    old = {k: os.environ.pop(k, None) for k in ('CRAY_HYBRID', 'CRAY_RECORDS_B0', 'CRAY_RECORDS_REST')}
     try:
-        ctx = backend.Context(0)
+        return backend.Context(0)
     finally:
-        if old is not None:
-            os.environ['CRAY_HYBRID'] = old
+        for k, v in old.items():
+            if v is not None:
+                os.environ[k] = v
+
+
+def test_a_context_that_chooses_its_records_per_scene_renders_the_same_film():
+    """Default contexts (CRAY_HYBRID unset) choose a scene's records BEFORE its first frame that is big enough to time, from a few
+    small probe passes on both kinds (cray_hip.hip probe_trace_records), per launch kind; cray_stats.trace_records says which
+    records a call read.  The choice must never show in the film — every frame equals the oracle's, bit for bit —, it is made once
+    (every later frame reads the same records, also after a counting frame, which always reads f64 records), and frames too small
+    to time stay on f64 records and choose nothing."""
+    ctx = _default_context()
     from craytracer_amd import scenes
     sc = scenes.dragon(512, 288, 16, 6, nu=200, nv=500)          # 2.36 M paths: big enough to be timed
     dev = ctx.upload(backend.HostScene(sc, resident=True))
     ref, _ = ol.OracleScene(sc).render(seed=2)
     seen = []
-    for _ in range(4):
+    for _ in range(3):
         f, st = dev.render(seed=2)
         assert np.array_equal(f, ref)
         seen.append(st['trace_records'])
-    assert seen[0] == 0x00 and seen[1] == 0x11, seen                       # the two timed frames
-    assert seen[2] == seen[3] and (seen[2] & 15) in (0, 1) and (seen[2] >> 4) in (0, 1), seen   # the choice, kept
+    assert (seen[0] & 15) in (0, 1) and (seen[0] >> 4) in (0, 1), seen      # the first frame already reads the chosen records
+    assert seen[1] == seen[0] and seen[2] == seen[0], seen                   # ... and so does every later one
     fc, stc = dev.render(seed=2, count_traversal=True)                       # counting frames always read f64 records
     assert stc['trace_records'] == 0 and np.array_equal(fc, ref)
+    f, st = dev.render(seed=2)                                               # ... and leave the scene's choice alone
+    assert st['trace_records'] == seen[0] and np.array_equal(f, ref)
     dev.close()
     small = ctx.upload(backend.HostScene(dict(small_scenes())['cornell']))
     for _ in range(3):
         assert small.render(seed=1)[1]['trace_records'] == 0
     small.close()
     ctx.close()
+
+
+def test_pinned_records_are_what_a_call_reads():
+    """CRAY_RECORDS_B0 / CRAY_RECORDS_REST pin the records per launch kind (hosts that want run-to-run identical kernels,
+    INTEGRATION.md; the profiling passes): no probe, every frame reads what was pinned, same film."""
+    import os
+    from craytracer_amd import scenes
+    sc = scenes.dragon(512, 288, 16, 6, nu=200, nv=500)
+    ref, _ = ol.OracleScene(sc).render(seed=2)
+    for b0, rest in (('1', '0'), ('0', '1')):
+        old = {k: os.environ.get(k) for k in ('CRAY_HYBRID', 'CRAY_RECORDS_B0', 'CRAY_RECORDS_REST')}
+        os.environ.pop('CRAY_HYBRID', None)
+        os.environ['CRAY_RECORDS_B0'] = b0
+        os.environ['CRAY_RECORDS_REST'] = rest
+        try:
+            ctx = backend.Context(0)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        dev = ctx.upload(backend.HostScene(sc, resident=True))
+        for _ in range(2):
+            f, st = dev.render(seed=2)
+            assert st['trace_records'] == (int(b0) | (int(rest) << 4)) and np.array_equal(f, ref)
+        dev.close()
+        ctx.close()
 
 
 @pytest.mark.parametrize('records', ['0', '1'])

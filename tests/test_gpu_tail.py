@@ -4,7 +4,11 @@ order and a helper's winning hit is certified (every box on its path has a key b
 again alone.  Films, per-ray records and ray counts must be the oracle's with the instantiation on (default) and off
 (CRAY_TAIL_RAYS=0), on scenes whose launches are all small, including the scene built around the reference's leak
 (scenes/rounding-error.cry: origins a hair outside a box) and rays that start exactly on box planes.
-Seam: Bvh::intersect, src/bvh.rs:58-104; Bounds::intersects, src/bounds.rs:62-88."""
+Seam: Bvh::intersect, src/bvh.rs:58-104; Bounds::intersects, src/bounds.rs:62-88.
+
+Round 5: the instantiation is exact and slower, so it is compiled only with -DCRAY_WITH_EXPERIMENTS
+(tools/build_variant.sh tail -DCRAY_WITH_EXPERIMENTS); run these tests against such a build with
+CRAY_LIB=exp/tail.so CRAY_WITH_EXPERIMENTS=1.  The default build ignores CRAY_TAIL_RAYS."""
 import os
 
 import numpy as np
@@ -14,7 +18,8 @@ from craytracer_amd import backend, scenes
 from oracle import oracle_lib as ol
 from tests.parity_util import small_scenes, random_rays
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get('CRAY_WITH_EXPERIMENTS') != '1', reason='the small-launch instantiation is not in the default build')]
 
 
 def _ctx(tail_rays):
