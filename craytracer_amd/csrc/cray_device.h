@@ -91,7 +91,6 @@ static_assert(sizeof(InnerNodeH) == 64, "InnerNodeH is four 16-B loads");
 //         rounded up, the id words
 //     X   one LeafExactH per leaf slot: the f64 triangle of the exact test, 80 B — at a 128-B stride (one line per record) next to a C
 //         region, packed at 80 B without one
-//     R   a copy of inner[] (128 B per interior node): the f64 bounds a RESOLVE step reads
 // A leaf reference names the leaf's first C record (arena_cull) or X record; the X record of the slot whose C record sits at offset c
 // is at 2 c + DevScene::arena_xk (both regions are indexed by slot, strides 64 and 128).
 constexpr uint32_t kHLeaf = 8u;
@@ -144,7 +143,6 @@ struct DevScene {
     uint32_t bounds_in_div_range;  // every node bound is 0 or within [2^-500, 2^500]: div_fast is exact
     uint32_t root_ref_h;           // root_ref in the arena's encoding (set with innerh)
     uint32_t arena_xk, arena_xstep;   // X record of the slot with C record at c: 2 c + arena_xk; bytes from an X record to the next
-    uint32_t arena_rbase, pad_arena_; // region R: a copy of inner[] (the f64 bounds of a RESOLVE), so that every fetch is arena + 32-bit offset
     const InnerNode* inner;
     const LeafSlot* slots;
     const InnerNode32* inner32;   // fast mode only (built on first use)

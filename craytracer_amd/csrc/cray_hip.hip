@@ -1061,8 +1061,7 @@ int ensure_inner32(cray_ctx* c, cray_scene* s) {
 // use: ONE allocation, n_inner InnerNodeH followed by one LeafRecH per leaf slot (cray_device.h), references = byte offsets.
 size_t arena_bytes(const cray_ctx* c, const cray_scene* s) {
     const uint64_t n_inner = s->dev.n_inner ? s->dev.n_inner : 1u, n_slots = (uint64_t)s->n_slots + 1u;   // + the zero pad slot of the f64 layout
-    const uint64_t leaves = (n_slots * (c->tri_cull ? kLeafCullStride + kLeafExactStride : kLeafExactPacked) + 127u) & ~(uint64_t)127u;
-    return (size_t)(n_inner * sizeof(InnerNodeH) + leaves + n_inner * sizeof(InnerNode));
+    return (size_t)(n_inner * sizeof(InnerNodeH) + n_slots * (c->tri_cull ? kLeafCullStride + kLeafExactStride : kLeafExactPacked));
 }
 bool hybrid_possible(const cray_ctx* c, const cray_scene* s) {
     // a reference is a 32-bit offset; twice the offset of a C record must not wrap (x = 2 c + xk and back)
@@ -1087,13 +1086,10 @@ int ensure_hybrid(cray_ctx* c, cray_scene* s, int level) {
                            reinterpret_cast<LeafCullH*>(arena + c_base), arena + x_base, x_stride);
     else
         HIP_TRY(hipMemcpyAsync(arena + x_base, s->dev.slots, (size_t)n_slots * sizeof(LeafSlot), hipMemcpyDeviceToDevice, c->stream));   // the slots as they are
-    const size_t r_base = bytes - (size_t)n_inner * sizeof(InnerNode);
-    HIP_TRY(hipMemcpyAsync(arena + r_base, s->dev.inner, (size_t)n_inner * sizeof(InnerNode), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipGetLastError());
     s->bytes += bytes;
     s->dev.innerh = reinterpret_cast<const InnerNodeH*>(arena);
-    s->dev.arena_rbase = (uint32_t)r_base;
     s->dev.root_ref_h = href_of(s->dev.root_ref, c_base, leaf_stride);
     s->dev.arena_cull = c->tri_cull ? 1u : 0u;
     s->dev.arena_xk = x_base - 2u * c_base;   // (mod 2^32: x = 2 c + xk holds in 32-bit arithmetic)
