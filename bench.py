@@ -55,7 +55,7 @@ WORKLOADS = {
 }
 
 
-RECORD_NAMES = ['f64', 'certified f32 culling', 'pair lines'] + ['?'] * 13
+RECORD_NAMES = ['f64', 'certified f32 culling'] + ['?'] * 14
 
 
 def make_scene(scenes, name):
@@ -105,7 +105,11 @@ def exchange_comm_id(backend, rank, world):
     return cid, store
 
 
-def committed_traffic(workload, lib_hash, launches_per_frame, world=1, precision='f64', path=None):
+# environment variables that select another library or other kernel instantiations / launch shapes than the profiled default
+INSTANTIATION_ENV = ('CRAY_LIB', 'CRAY_HYBRID', 'CRAY_STEAL', 'CRAY_LDS_SHAPES', 'CRAY_MIX_TRACE', 'CRAY_TRI_CULL', 'CRAY_TAIL_RAYS', 'CRAY_SHADE_VARIANT')
+
+
+def committed_traffic(workload, lib_hash, launches_per_frame, world=1, precision='f64', path=None, records=None, environ=None):
     """HBM bytes per traversal launch from the committed counter profile (profiles/hbm_traffic.json) — but only when that profile
     is of the very build of the kernels this process runs: `lib_hash` is the source hash stamped on the loaded library, the
     profile carries the hash of the library that was profiled (tools/profile_round.sh + tools/adopt_profile.sh).  Any other
@@ -130,6 +134,18 @@ def committed_traffic(workload, lib_hash, launches_per_frame, world=1, precision
                   'method': 'FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 from separate rocprofv3 --pmc passes (tools/traffic_from_pmc.py)'}
     if not prof_hash or prof_hash != lib_hash:
         provenance['refused'] = 'the committed counters are of another build of the kernels: re-run tools/profile_round.sh'
+        return None, provenance, ent
+    # ... and of the very instantiations: which kernels run is decided at run time (the records a scene's probe passes chose or the
+    # environment pinned, CRAY_LIB, the instantiation switches), and the counter passes were pinned to ONE such choice
+    env = os.environ if environ is None else environ
+    odd = sorted(k for k in INSTANTIATION_ENV if env.get(k))
+    if odd:
+        provenance['refused'] = 'this run selects its library / kernel instantiations through %s: the committed counters are of the default ones' % ', '.join(odd)
+        return None, provenance, ent
+    pinned = ent.get('records')
+    provenance['profiled_records'] = pinned
+    if records is not None and pinned is not None and dict(records) != dict(pinned):
+        provenance['refused'] = 'the timed frames read other traversal records (%s) than the profiled passes were pinned to (%s)' % (dict(records), dict(pinned))
         return None, provenance, ent
     # per launch of THIS run: the profiled frame's traversal traffic over this run's launches per frame (the pass plan, hence
     # the number of launches, depends on the path pool; the bytes per frame do not)
@@ -240,8 +256,18 @@ def main():
         ctx.barrier()               # all-reduce over RCCL + stream sync (a stream sync alone when N = 1)
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # the first cray_render of the process: the path pool is allocated (the driver clears it: ~20 ms per GiB), the scene's traversal
+    # records are chosen from probe passes, the tile order is probed — what a host that renders one frame per process (the reference's
+    # own usage, craytracer.rs:336-372) pays on top of the steady state the timed steps measure
+    first_frame_ms = None
+    for i in range(args.warmup):
+        if i == 0:
+            torch.cuda.synchronize()
+            tf = time.perf_counter()
         frame()
+        if i == 0:
+            torch.cuda.synchronize()
+            first_frame_ms = (time.perf_counter() - tf) * 1e3
     barrier()
     t_start = time.perf_counter()
     stats = []
@@ -329,7 +355,8 @@ def main():
         # HBM bytes the PMC counters saw for these kernels.  Counters need their own rocprofv3 --pmc passes, so this run cannot
         # measure them: they come from the committed profile of THIS build (tools/profile_round.sh -> profiles/hbm_traffic.json),
         # and are refused when the profile is of another build (source hash of the kernels differs from the loaded library's).
-        traffic_frame, provenance, ent = committed_traffic(args.workload, hip_build.loaded_kernel_hash(), 1.0, world, args.precision)
+        rec_now = {'bounce0': RECORD_NAMES[stats[-1]['trace_records'] & 15], 'other_launches': RECORD_NAMES[(stats[-1]['trace_records'] >> 4) & 15]}
+        traffic_frame, provenance, ent = committed_traffic(args.workload, hip_build.loaded_kernel_hash(), 1.0, world, args.precision, records=rec_now)
 
         def block(kernel, ms, launches, hbm_per_frame, alg_frame, n_rays):
             per_frame = launches / max(1, args.steps)
@@ -367,7 +394,8 @@ def main():
         roofline['traffic_provenance'] = provenance
         roofline['bound_note'] = ('HBM is the roofline the north star prices this path against; the counters of the same build say what binds the kernel '
                                   'is per CU: VALU issue first (the time follows the instruction count, DESIGN.md 3.4), L1 line fills and the texture addresser '
-                                  'as co-limits: other_bounds')
+                                  'as co-limits: other_bounds.  `traffic` is FETCH_SIZE x 2 + WRITE_SIZE: on gfx950 FETCH_SIZE appears to count reads served by '
+                                  'the Infinity Cache as well (MI355X_MICROARCH.md), so `achieved` / `frac` are an UPPER bound of the DRAM traffic')
         if traffic_frame and ent.get('units'):
             # utilisations of the units that do bind the path, from the SQ / TA / TCC / TCP passes of the same profiled build
             u = ent['units']
@@ -460,6 +488,10 @@ def main():
  'parallelism': ('tile-shard x%d (32x32 tiles, tile %% N == rank); C ABI: cray_comm_init + %s + cray_render_gather (RCCL ncclSend/ncclRecv of Film tiles to rank 0)'
                                        % (world, 'per-rank scene build' if args.replicate_host else 'cray_scene_broadcast (ncclBroadcast)')) if world > 1 else 'single GPU',
                        'seconds_per_frame': round(elapsed / args.steps, 4),
+                       # the cold frame (rank 0): first cray_render of the process, pool allocation + record choice + tile probe included
+                       'first_frame_ms': round(first_frame_ms, 1) if first_frame_ms is not None else None,
+                       'pool_bytes': ctx.pool_info()[0], 'pool_paths': ctx.pool_info()[1],
+                       'trace_records_choice': dev.records_info(),
                        'mpaths_per_s': round(total_paths / elapsed / 1e6, 2),
                        'rays_per_frame': int(total_rays / args.steps),
                        'reference_queries_per_frame': int(total_queries / args.steps),
@@ -471,8 +503,8 @@ def main():
                                    'shade': round(kern[5] / args.steps, 2), 'other': round(kern[6] / args.steps, 2),
                                    'note': "rank 0's share" if world > 1 else 'whole frame',
                                    # which records the traversal launches of the timed frames read (cray_stats.trace_records): both give
-                                   # the reference's hits bit for bit; the library keeps per scene and launch kind whichever its first
-                                   # two frames showed to be faster
+                                   # the reference's hits bit for bit; the library keeps per scene and launch kind whichever its probe
+                                   # passes before the scene's first frame showed to be faster (config.trace_records_choice)
                                    'trace_records': {'bounce0': RECORD_NAMES[stats[-1]['trace_records'] & 15],
                                                      'other_launches': RECORD_NAMES[(stats[-1]['trace_records'] >> 4) & 15]}},
         }

@@ -498,6 +498,8 @@ extern "C" {
     pub fn cray_tile_pixels(width: u32, height: u32, tile_width: u32, tile_height: u32, rank: u32, world_size: u32,
                             out: *mut u32, capacity: u64, n_pixels: *mut u64) -> c_int;
     pub fn cray_measure_stream_read(ctx: *mut CrayCtx, bytes: u64, repeats: c_int, gb_per_s: *mut f64) -> c_int;
+    pub fn cray_ctx_pool_info(ctx: *const CrayCtx, pool_bytes: *mut u64, paths: *mut u64);
+    pub fn cray_scene_records_info(scene: *const CrayScene, chosen: *mut i32, probe_ms: *mut f64, probe_kernel_ms: *mut f64);
     pub fn cray_last_error() -> *const c_char;
 
     // ---- include/cray_host.h: Scene::new in C++ for hosts that are not craytracer itself ----

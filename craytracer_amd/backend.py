@@ -89,7 +89,7 @@ ABI_SYMBOLS = ['cray_ctx_create', 'cray_ctx_destroy', 'cray_scene_upload', 'cray
                'cray_cry_parse_scene', 'cray_owned_scene_desc', 'cray_owned_scene_warnings', 'cray_owned_scene_free',
                'cray_scene_info', 'cray_comm_unique_id', 'cray_comm_init', 'cray_comm_rank', 'cray_comm_world_size',
                'cray_comm_barrier', 'cray_comm_allreduce_f64', 'cray_comm_describe', 'cray_scene_broadcast', 'cray_render_gather',
-               'cray_film_gather', 'cray_film_pack', 'cray_film_unpack', 'cray_measure_stream_read', 'cray_load_image', 'cray_free_image', 'cray_default_image_loader', 'cray_set_sobol_vectors',
+               'cray_film_gather', 'cray_film_pack', 'cray_film_unpack', 'cray_measure_stream_read', 'cray_ctx_pool_info', 'cray_scene_records_info', 'cray_load_image', 'cray_free_image', 'cray_default_image_loader', 'cray_set_sobol_vectors',
                'cray_host_scene_new_resident', 'cray_scene_build_stats', 'cray_tile_pixels', 'cray_preview_checkerboard', 'cray_preview_pixels']
 
 _lib = None
@@ -343,6 +343,15 @@ class Context:
             return device_scene
         return DeviceScene(self, None, handle=out)
 
+    def pool_info(self):
+        """(bytes of the path-state pool this context holds, paths it has room for): cray_ctx_pool_info"""
+        b, n = C.c_uint64(0), C.c_uint64(0)
+        L = lib()
+        L.cray_ctx_pool_info.restype = None
+        L.cray_ctx_pool_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.cray_ctx_pool_info(self._h, C.byref(b), C.byref(n))
+        return b.value, n.value
+
     def measure_stream_read(self, nbytes=4 << 30, repeats=5):
         """GB/s of a plain 16-B/lane streaming read on this GPU (cray_measure_stream_read)."""
         g = C.c_double(0.0)
@@ -419,6 +428,16 @@ class DeviceScene:
     #: (tile_width, tile_height) of the shard and of the pixel order inside a pass; None = the reference's 64 x 64 (craytracer.rs:232-233).
     #: The film does not depend on it; 32 x 32 balances the ranks of a multi-GPU frame better.
     tile = None
+
+    def records_info(self):
+        """cray_scene_records_info: {'chosen': (bounce 0, others) with -1 = nothing chosen, 'probe_ms', 'probe_kernel_ms': {...}}"""
+        L = lib()
+        L.cray_scene_records_info.restype = None
+        L.cray_scene_records_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        ch, ms, k = (C.c_int32 * 2)(), C.c_double(0.0), (C.c_double * 4)()
+        L.cray_scene_records_info(self._h, ch, C.byref(ms), k)
+        return {'chosen': (ch[0], ch[1]), 'probe_ms': ms.value,
+                'probe_kernel_ms': {'f64': {'bounce0': k[0], 'other_launches': k[1]}, 'f32_culling': {'bounce0': k[2], 'other_launches': k[3]}}}
 
     def params(self, seed=0, rank=0, world_size=1, sample_range=None, count_traversal=False, max_paths_in_flight=0):
         p = RenderParams()

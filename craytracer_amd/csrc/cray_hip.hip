@@ -413,6 +413,30 @@ extern "C" int cray_ctx_create(int device_id, void* stream, cray_ctx** out) {
     c->trace_blocks_per_cu = env_int("CRAY_TRACE_BLOCKS_PER_CU", 1, 16, c->trace_blocks_per_cu);
     c->shade_blocks_per_cu = env_int("CRAY_SHADE_BLOCKS_PER_CU", 0, 64, c->shade_blocks_per_cu);
     c->trace32_blocks_per_cu = env_int("CRAY_TRACE32_BLOCKS_PER_CU", 1, 16, c->trace32_blocks_per_cu);
+    {
+        // the kernels read their path-state pointers straight from the kernel-argument segment (cray_kernels.h ps_kernarg): check once
+        // that the offsets computed there are where the compiler put the arguments
+        DevScene probe_sc;
+        memset(&probe_sc, 0, sizeof(probe_sc));
+        probe_sc.max_depth = 0x5a5a5a5au;
+        PathState a, b;
+        memset(&a, 0, sizeof(a));
+        memset(&b, 0, sizeof(b));
+        a.ox = reinterpret_cast<double*>(0x1000); a.hprim = reinterpret_cast<int32_t*>(0x2000); a.sprim = reinterpret_cast<int32_t*>(0x3000); a.lr = reinterpret_cast<double*>(0x4000);
+        b.ox = reinterpret_cast<double*>(0x5000); b.hprim = reinterpret_cast<int32_t*>(0x6000); b.sprim = reinterpret_cast<int32_t*>(0x7000); b.lr = reinterpret_cast<double*>(0x8000);
+        uint32_t* d_bad = reinterpret_cast<uint32_t*>(&c->counters->pad_head_);
+        uint32_t bad = ~0u;
+        hipLaunchKernelGGL(k_kernarg_check, dim3(1), dim3(64), 0, c->stream, probe_sc, a, b, d_bad);
+        hipError_t err = hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, c->stream);
+        if (err == hipSuccess) err = hipStreamSynchronize(c->stream);
+        if (err != hipSuccess || bad != 0u) {
+            set_last_error("kernel-argument layout check failed (%s, code %u): the path-state views are not where cray_kernels.h ps_kernarg() expects them",
+                           err != hipSuccess ? hipGetErrorString(err) : "mismatch", bad);
+            cray_ctx_destroy(c);
+            return CRAY_ERR_HIP;
+        }
+        (void)hipMemsetAsync(d_bad, 0, sizeof(uint32_t), c->stream);
+    }
     *out = c;
     return CRAY_OK;
 }
@@ -1673,6 +1697,9 @@ extern "C" int cray_render_samples(cray_ctx* c, cray_scene* s, const cray_render
         c->film_floats = film_floats;
     }
     if ((e = ensure_state(c, n_pix * n))) return e;
+    // the records THIS scene's launches read (what an earlier cray_render left in use_* belongs to that call): pinned, chosen, or f64
+    if ((e = choose_trace_records(c, s, prm->count_traversal != 0 || prm->precision != CRAY_PRECISION_F64, n_pix * n, nullptr))) return e;
+    if ((e = ensure_tail(c, s))) return e;
     HIP_TRY(hipMemcpyAsync(c->pix_list, pix.data(), pix.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->film, 0, film_floats * sizeof(float), c->stream));
     if ((e = reset_counters(c))) return e;
@@ -2142,6 +2169,16 @@ __global__ void __launch_bounds__(kBlock) k_stream_read(const double2* __restric
         acc += v.x + v.y;
     }
     if (acc == 123.456) *sink = acc;  // keeps the loads alive; never true for the zero-filled buffer
+}
+
+extern "C" void cray_ctx_pool_info(const cray_ctx* c, uint64_t* pool_bytes, uint64_t* paths) {
+    if (pool_bytes) *pool_bytes = c ? (uint64_t)c->capacity * kBytesPerPath : 0;
+    if (paths) *paths = c ? (uint64_t)c->capacity : 0;
+}
+extern "C" void cray_scene_records_info(const cray_scene* s, int32_t chosen[2], double* probe_ms, double probe_kernel_ms[4]) {
+    if (chosen) { chosen[0] = s ? s->chosen_b0 : -1; chosen[1] = s ? s->chosen_rest : -1; }
+    if (probe_ms) *probe_ms = s ? s->probe_ms : 0.0;
+    if (probe_kernel_ms) for (int v = 0; v < 2; v++) for (int k = 0; k < 2; k++) probe_kernel_ms[2 * v + k] = s ? s->tune_ms[v][k] : 0.0;
 }
 
 extern "C" int cray_measure_stream_read(cray_ctx* c, uint64_t bytes, int repeats, double* gb_per_s) {

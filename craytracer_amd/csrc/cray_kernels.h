@@ -93,6 +93,20 @@ constexpr size_t kPsArgOffset = (sizeof(DevScene) + alignof(PathState) - 1) / al
 __device__ __forceinline__ PsArg ps_kernarg() {
     return (PsArg)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + kPsArgOffset);
 }
+// What ties ps_kernarg() to the kernel signatures: a kernel with the same leading arguments as k_trace / k_trace_mixed (DevScene,
+// PathState) and k_shade (DevScene, PathState, PathState) compares what it reads from the kernel-argument segment at the
+// hand-computed offsets with the by-value arguments themselves.  cray_ctx_create launches it once and refuses the context on a
+// mismatch — a reordered signature or another by-value lowering would otherwise show as a memory fault in the middle of a frame.
+__global__ void k_kernarg_check(DevScene sc, PathState ps, PathState po, uint32_t* __restrict__ bad) {
+    const PsArg a = ps_kernarg();
+    const PsArg b = (PsArg)((const char __attribute__((address_space(4)))*)a + sizeof(PathState));
+    uint32_t e = 0;
+    e |= (a->ox != ps.ox || a->hprim != ps.hprim || a->sprim != ps.sprim || a->lr != ps.lr) ? 1u : 0u;
+    e |= (b->ox != po.ox || b->hprim != po.hprim || b->sprim != po.sprim || b->lr != po.lr) ? 2u : 0u;
+    e |= sc.max_depth != 0x5a5a5a5au ? 4u : 0u;
+    if (threadIdx.x == 0 && blockIdx.x == 0) *bad = e;
+}
+
 template <int MODE, bool COUNT, int HYB, bool SHAPES_LDS = false, bool TAIL = false>
 __device__ __forceinline__ void trace_body(const DevScene& sc, const PsArg ps_arg, const uint32_t* __restrict__ queue, const uint32_t n_first,
                                            const uint32_t* __restrict__ queue_b, const uint32_t n_b, const double* __restrict__ closest_tmax,
@@ -120,7 +134,7 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PsArg ps_ar
 #ifndef CRAY_CULL_HITS
 #define CRAY_CULL_HITS 1   // any-hit lanes end at a triangle whose f32 copy certifies the HIT (no distance is needed); 0: A/B builds
 #endif
-    constexpr bool kCullHits = MODE != kTraceClosest && CRAY_CULL_HITS != 0;
+    [[maybe_unused]] constexpr bool kCullHits = MODE != kTraceClosest && CRAY_CULL_HITS != 0;
     constexpr bool STEAL = !COUNT && !HYB && (MODE == kTraceAny || TAIL);
     const bool steal_on = STEAL && (refill_min & 0x8000u) != 0;
     unsigned int age = 0, age_min = 0;   // TAIL: iterations this lane's segment has been walked / before it may hand parts out
@@ -233,8 +247,8 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PsArg ps_ar
     float t_lo = 0.f, t_hi = 0.f;
     uint32_t res = 0;
     bool resolve = false;
-    bool lexact = false;     // HYB: the slot `cur` names was not decided by its f32 copy — its f64 triangle is tested next
-    float d32x = 0.f, d32y = 0.f, d32z = 1.f;   // HYB: RN32 of ray.d (tri_cull32)
+    [[maybe_unused]] bool lexact = false;     // HYB: the slot `cur` names was not decided by its f32 copy — its f64 triangle is tested next
+    [[maybe_unused]] float d32x = 0.f, d32y = 0.f, d32z = 1.f;   // HYB: RN32 of ray.d (tri_cull32)
 
     if constexpr (HYB != 0) {
         // (how the loop is spelled: see the head of cray_trace_step.inc)

@@ -148,9 +148,9 @@ typedef struct {
     double trace_closest_ms, trace_any_ms, shade_ms, other_ms; /* HIP-event time per kernel family */
     uint32_t trace_closest_launches, trace_any_launches, shade_launches;
     uint32_t trace_records;                 /* which records the traversal launches of this call read: low nibble the bounce-0
-                                               launch, next nibble the others; 0 f64, 1 certified f32 culling, 2 pair lines.  The
-                                               hits are the reference's either way; by default the library picks per
-                                               scene whichever its first two frames show to be faster */
+                                               launch, next nibble the others; 0 f64, 1 certified f32 culling.  The hits are the
+                                               reference's either way; by default the library picks per scene
+                                               whichever a few probe passes before the scene's first frame show to be faster */
     double trace_mixed_ms;                  /* launches that trace the shadow rays of bounce b together with the
                                                path segments of bounce b+1 (not used with count_traversal) */
     uint32_t trace_mixed_launches;
@@ -304,6 +304,16 @@ int cray_film_unpack(cray_ctx* ctx, uint32_t width, uint32_t height, uint32_t ti
  * the order of cray_film_pack's output and of the buffer cray_render_gather sends.  out may be NULL to query *n_pixels. */
 int cray_tile_pixels(uint32_t width, uint32_t height, uint32_t tile_width, uint32_t tile_height, uint32_t rank, uint32_t world_size,
                      uint32_t* out, uint64_t capacity, uint64_t* n_pixels);
+
+/* Diagnostics for bench lines and cold-start accounting (the reference renders one frame per process, craytracer.rs:336-372):
+ *   cray_ctx_pool_info       bytes of the path-state pool the context holds (allocated by its first cray_render, then kept) and the
+ *                            paths it has room for; any pointer may be NULL
+ *   cray_scene_records_info  what the scene's traversal launches read: chosen[2] = records of the bounce-0 launch / of the others
+ *                            (0 f64, 1 certified f32 culling, -1 nothing chosen yet: pinned, or no frame big enough to time so far),
+ *                            probe_ms = wall time of the probe passes that chose them (once per scene), and probe_kernel_ms[4] = best
+ *                            time of those passes' bounce-0 launch / other traversal launches on f64 records, then on f32 culling */
+void cray_ctx_pool_info(const cray_ctx* ctx, uint64_t* pool_bytes, uint64_t* paths);
+void cray_scene_records_info(const cray_scene* scene, int32_t chosen[2], double* probe_ms, double probe_kernel_ms[4]);
 
 /* Measurement aid for bench.py: GB/s of a plain 16-B-per-lane streaming read of `bytes` of HBM on this GPU (HIP events,
  * `repeats` launches after one warm-up) — the denominator "what a read-only kernel gets on this very box". */

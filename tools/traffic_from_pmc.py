@@ -73,6 +73,8 @@ if __name__ == '__main__':
             if line.startswith('{'):
                 entry['source_hash'] = json.loads(line)['config']['build'].get('source_hash')
                 entry['kernel_hash'] = json.loads(line)['config']['build'].get('kernel_hash')
+                # the records the profiled passes were pinned to (tools/profile_round.sh): bench.py refuses the figure for frames that read others
+                entry['records'] = json.loads(line).get('kernel_ms_per_step', {}).get('trace_records')
     data[workload] = entry
     json.dump(data, open(path, 'w'), indent=1)
     print(json.dumps(entry, indent=1))
