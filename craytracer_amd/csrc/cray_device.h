@@ -82,35 +82,16 @@ struct alignas(64) InnerNodeH {
     uint32_t ref0, ref1, axis, pad_;
 };
 static_assert(sizeof(InnerNodeH) == 64, "InnerNodeH is four 16-B loads");
-// ---- round 5: the certified-f32 records of a scene live in ONE arena and a child reference of an InnerNodeH IS the byte offset (a
-// multiple of 16) of what a lane fetches next, | kHLeaf | (count - 1) for a leaf (count in 1..8): the fetch address of every common
-// traversal state is arena + (ref & ~15) — one instruction.  Regions of the arena:
-//     I   n_inner InnerNodeH (64 B)
-//     C   one LeafCullH (64 B) per leaf slot — only when the launches cull triangles from their f32 copies first (DevScene::arena_cull):
-//         the f64 v0 (the culling subtracts it from the origin in f64, cray_math.h tri_cull32), RN32 of the edges, their max-norms
-//         rounded up, the id words
-//     X   one LeafExactH per leaf slot: the f64 triangle of the exact test, 80 B — at a 128-B stride (one line per record) next to a C
-//         region, packed at 80 B without one
-// A leaf reference names the leaf's first C record (arena_cull) or X record; the X record of the slot whose C record sits at offset c
-// is at 2 c + DevScene::arena_xk (both regions are indexed by slot, strides 64 and 128).
+// ---- round 5: the certified-f32 records of a scene live in ONE arena — n_inner InnerNodeH, then the leaf slots (LeafSlot, 80 B, as in
+// slots[]) — and a child reference of an InnerNodeH IS the byte offset (a multiple of 16) of what a lane fetches next:
+//     interior child:  offset of its InnerNodeH
+//     leaf child:      offset of its first slot | kHLeaf | (count - 1),  count in 1..8
+// so the fetch address of an interior node or a leaf slot is arena + (ref & ~15): one instruction where the three arrays of rounds
+// 2-4 took seventeen (three kinds of index, three bases behind selects).  k_trace_mixed 111.4 -> 108.0 ms, bounce 0 23.2 -> 22.4.
 constexpr uint32_t kHLeaf = 8u;
 CRAY_HD bool href_is_leaf(uint32_t r) { return (r & kHLeaf) != 0; }
 CRAY_HD uint32_t href_off(uint32_t r) { return r & ~15u; }
 CRAY_HD uint32_t href_more(uint32_t r) { return r & 7u; }   // slots of the leaf after this one
-struct alignas(16) LeafCullH {
-    uint32_t prim, kind;
-    double v0[3];               // (sphere / disk slots: the shape index in the bits of v0[0], the rest zero)
-    float e1f[3], e2f[3];       // RN32 of the edges
-    float e1m, e2m;             // max |e1_i|, max |e2_i| of the f64 edges, rounded UP
-};
-static_assert(sizeof(LeafCullH) == 64, "LeafCullH is four 16-B loads");
-struct alignas(16) LeafExactH {
-    double e1[3], e2[3];
-    uint32_t prim, kind;
-    double v0[3];
-};
-static_assert(sizeof(LeafExactH) == 80, "LeafExactH is five 16-B loads");
-constexpr uint32_t kLeafCullStride = 64u, kLeafExactStride = 128u, kLeafExactPacked = 80u;
 
 struct TriShade {
     double n0[3], n01[3], n02[3];
@@ -142,11 +123,10 @@ struct DevScene {
     uint32_t root_ref, n_inner;
     uint32_t bounds_in_div_range;  // every node bound is 0 or within [2^-500, 2^500]: div_fast is exact
     uint32_t root_ref_h;           // root_ref in the arena's encoding (set with innerh)
-    uint32_t arena_xk, arena_xstep;   // X record of the slot with C record at c: 2 c + arena_xk; bytes from an X record to the next
     const InnerNode* inner;
     const LeafSlot* slots;
     const InnerNode32* inner32;   // fast mode only (built on first use)
-    const InnerNodeH* innerh;     // certified f32 culling only (built on first use): the ARENA — n_inner InnerNodeH, then n_slots LeafRecH
+    const InnerNodeH* innerh;     // certified f32 culling only (built on first use): the ARENA — n_inner InnerNodeH, then the leaf slots
     const LeafSlot32* slots32;
     // primitives
     const cray_prim* prims;
@@ -161,8 +141,7 @@ struct DevScene {
     const uint8_t* pool;
     const double* gamma_lut;  // (c/255)^2.2 for c in 0..255 (Color::from_rgb, color.rs:39-46)
     uint32_t n_materials, n_bxdfs, n_textures, n_images, n_spheres, n_disks;
-    uint32_t shade_stage_shapes;   // the sphere / disk tables fit the staging area as well
-    uint32_t arena_cull;           // the arena has a C region and its leaf references point into it: the launches cull triangles from f32 copies first
+    uint32_t shade_stage_shapes, pad_tab_;   // the sphere / disk tables fit the staging area as well
     uint32_t shade_tables_bytes;  // > 0: materials + bxdfs + textures + lights + light tables fit k_shade's LDS staging area (bytes)
     // lights
     const DevLight* lights;

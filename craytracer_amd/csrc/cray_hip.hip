@@ -65,9 +65,6 @@ struct cray_ctx {
     // (profiles/r04_refill_sweep_f32_culling*.log)
     unsigned int refill_min_hyb = 20, refill_min_any_hyb = 20;
     unsigned int leaf_min = 10;    // lanes of a wave that must be at a leaf slot before the leaf step runs (mixed / any-hit launches; 0 or 1: no waiting)
-    // the same for the two leaf states of the certified-f32 launches (cray_trace_step_hyb.inc): the f32 culling of a slot, the exact test
-    unsigned int cull_min = 6, exact_min = 10;
-    unsigned int tri_cull = 0;     // CRAY_TRI_CULL=0: no f32 culling of triangles, a lane at a leaf slot runs the f64 test at once (read when a scene's arena is built)
     unsigned int lds_shapes = 1;   // the few sphere / disk records of a scene staged in LDS by the traversal launches (CRAY_LDS_SHAPES=0: read global memory)
     unsigned int steal = 1;   // work sharing among the lanes of a wave in the drain of the shadow-ray launches (trace_body, STEAL); CRAY_STEAL=0 turns it off
     int trace_blocks_per_cu = 4;
@@ -330,8 +327,8 @@ void fill_stats(const Counters& h, cray_stats* st) {
                 100.0 * g[2] / g[0], g[2] ? (double)g[3] / g[2] : 0.0, g[4], g[4] ? (double)g[5] / g[4] : 0.0);
         fprintf(stderr, "diag %s: iterations with a lane at a leaf %.1f%%, at a sphere / disk slot %.1f%% (%.2f lanes), at a leaf of several slots %.1f%%\n",
                 a ? "any" : "closest", 100.0 * g[10] / g[0], 100.0 * g[11] / g[0], (double)g[13] / g[0], 100.0 * g[12] / g[0]);
-        fprintf(stderr, "diag %s (certified-f32 launches read these as): culling step in %.1f%% of the iterations with %.2f lanes/iter; exact step in %.1f%% with %.2f lanes/iter; %.2f lanes/iter waiting\n",
-                a ? "any" : "closest", 100.0 * g[10] / g[0], (double)g[7] / g[0], 100.0 * g[11] / g[0], (double)g[12] / g[0], (double)g[13] / g[0]);
+        fprintf(stderr, "diag %s (certified-f32 launches read the second line as): every lane at an interior node on the SAME node in %.1f%% of the iterations; of %.1f such lanes %.1f share the first one's node\n",
+                a ? "any" : "closest", 100.0 * g[11] / g[0], (double)g[13] / g[0], (double)g[12] / g[0]);
         fprintf(stderr, "diag %s: pop loop entered in %.1f%% of the iterations, %.2f trips per entry (the wave runs the maximum over its lanes)\n",
                 a ? "any" : "closest", 100.0 * g[15] / g[0], g[15] ? (double)g[14] / g[15] : 0.0);
     }
@@ -404,9 +401,6 @@ extern "C" int cray_ctx_create(int device_id, void* stream, cray_ctx** out) {
     c->lds_shapes = (unsigned int)env_int("CRAY_LDS_SHAPES", 0, 1, (int)c->lds_shapes);
     c->tile_order = env_int("CRAY_TILE_ORDER", 0, 1, c->tile_order);
     c->leaf_min = (unsigned int)env_int("CRAY_LEAF_MIN", 0, 63, (int)c->leaf_min);
-    c->cull_min = (unsigned int)env_int("CRAY_CULL_MIN", 0, 63, (int)c->cull_min);
-    c->exact_min = (unsigned int)env_int("CRAY_EXACT_MIN", 0, 63, (int)c->exact_min);
-    c->tri_cull = (unsigned int)env_int("CRAY_TRI_CULL", 0, 1, (int)c->tri_cull);
     c->tail_rays = (unsigned int)env_int("CRAY_TAIL_RAYS", 0, (1 << 24) - 1, (int)c->tail_rays);
     c->tail_seg = (unsigned int)env_int("CRAY_TAIL_SEG", 0, 1, (int)c->tail_seg);
     c->tail_age = (unsigned int)env_int("CRAY_TAIL_AGE", 0, 255, (int)c->tail_age);
@@ -1083,41 +1077,30 @@ int ensure_inner32(cray_ctx* c, cray_scene* s) {
 }
 // Exact traversal with certified f32 culling: decided per scene (range of the bounds, size of the arena), records derived on first
 // use: ONE allocation, n_inner InnerNodeH followed by one LeafRecH per leaf slot (cray_device.h), references = byte offsets.
-size_t arena_bytes(const cray_ctx* c, const cray_scene* s) {
+size_t arena_bytes(const cray_scene* s) {
     const uint64_t n_inner = s->dev.n_inner ? s->dev.n_inner : 1u, n_slots = (uint64_t)s->n_slots + 1u;   // + the zero pad slot of the f64 layout
-    return (size_t)(n_inner * sizeof(InnerNodeH) + n_slots * (c->tri_cull ? kLeafCullStride + kLeafExactStride : kLeafExactPacked));
+    return (size_t)(n_inner * sizeof(InnerNodeH) + n_slots * sizeof(LeafSlot));
 }
-bool hybrid_possible(const cray_ctx* c, const cray_scene* s) {
-    // a reference is a 32-bit offset; twice the offset of a C record must not wrap (x = 2 c + xk and back)
-    const uint64_t c_end = ((uint64_t)(s->dev.n_inner ? s->dev.n_inner : 1u) + (uint64_t)s->n_slots + 1u) * 64u;
-    return s->dev.bounds_in_div_range && hyb_scene_ok(s->dev.root_lo, s->dev.root_hi) && arena_bytes(c, s) < ((size_t)1 << 32) && (!c->tri_cull || c_end < (1ull << 31));
+bool hybrid_possible(const cray_scene* s) {
+    // (a reference is a 32-bit offset into the arena: scenes beyond ~30 M triangles read the f64 records)
+    return s->dev.bounds_in_div_range && hyb_scene_ok(s->dev.root_lo, s->dev.root_hi) && arena_bytes(s) < ((size_t)1 << 32);
 }
 int ensure_hybrid(cray_ctx* c, cray_scene* s, int level) {
     if (level <= 0 || !s->hybrid_ok) return CRAY_OK;
     if (s->dev.innerh) return CRAY_OK;
     const uint32_t n_inner = s->dev.n_inner ? s->dev.n_inner : 1u, n_slots = s->n_slots + 1u;
-    const size_t bytes = arena_bytes(c, s);
+    const size_t bytes = arena_bytes(s);
     char* arena = nullptr;
     HIP_TRY(hipMalloc((void**)&arena, bytes));
     s->extra_allocs.push_back(arena);
-    const uint32_t c_base = n_inner * (uint32_t)sizeof(InnerNodeH);                                  // region C (or X when there is no culling)
-    const uint32_t x_base = c->tri_cull ? c_base + n_slots * kLeafCullStride : c_base;
-    const uint32_t x_stride = c->tri_cull ? kLeafExactStride : kLeafExactPacked;
-    const uint32_t leaf_stride = c->tri_cull ? kLeafCullStride : x_stride;
-    hipLaunchKernelGGL(k_make_innerh, dim3((n_inner + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, s->dev.inner, n_inner, reinterpret_cast<InnerNodeH*>(arena), c_base, leaf_stride);
-    if (c->tri_cull)
-        hipLaunchKernelGGL(k_make_leafh, dim3((n_slots + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, s->dev.slots, n_slots,
-                           reinterpret_cast<LeafCullH*>(arena + c_base), arena + x_base, x_stride);
-    else
-        HIP_TRY(hipMemcpyAsync(arena + x_base, s->dev.slots, (size_t)n_slots * sizeof(LeafSlot), hipMemcpyDeviceToDevice, c->stream));   // the slots as they are
+    const uint32_t leaf_base = n_inner * (uint32_t)sizeof(InnerNodeH);
+    hipLaunchKernelGGL(k_make_innerh, dim3((n_inner + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, s->dev.inner, n_inner, reinterpret_cast<InnerNodeH*>(arena), leaf_base);
+    HIP_TRY(hipMemcpyAsync(arena + leaf_base, s->dev.slots, (size_t)n_slots * sizeof(LeafSlot), hipMemcpyDeviceToDevice, c->stream));   // the slots as they are
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipGetLastError());
     s->bytes += bytes;
     s->dev.innerh = reinterpret_cast<const InnerNodeH*>(arena);
-    s->dev.root_ref_h = href_of(s->dev.root_ref, c_base, leaf_stride);
-    s->dev.arena_cull = c->tri_cull ? 1u : 0u;
-    s->dev.arena_xk = x_base - 2u * c_base;   // (mod 2^32: x = 2 c + xk holds in 32-bit arithmetic)
-    s->dev.arena_xstep = x_stride;
+    s->dev.root_ref_h = href_of(s->dev.root_ref, leaf_base);
     return CRAY_OK;
 }
 // The records this call's traversal launches read.  Pinned by CRAY_HYBRID / ctx->hybrid >= 0 or CRAY_RECORDS_B0 / _REST; otherwise
@@ -1125,7 +1108,7 @@ int ensure_hybrid(cray_ctx* c, cray_scene* s, int level) {
 // the caller runs probe_trace_records before its first pass.  Never touches the choice itself.
 int choose_trace_records(cray_ctx* c, cray_scene* s, bool counting, size_t n_paths, bool* want_probe) {
     if (want_probe) *want_probe = false;
-    s->hybrid_ok = hybrid_possible(c, s);
+    s->hybrid_ok = hybrid_possible(s);
     if (!s->hybrid_ok) { s->use_b0 = s->use_rest = 0; return CRAY_OK; }
     if (c->hybrid >= 0) {
         s->use_b0 = s->use_rest = c->hybrid;
@@ -1295,8 +1278,7 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
                                          (const uint32_t*)q_next, (const unsigned int*)n_next, ctr, &ctr->trace_head, c->refill_min, 0u);
             else launch_mixed(s->use_rest, shp, c->tail_res != nullptr, g_trace, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, (const uint32_t*)q_next,
                               (const unsigned int*)n_next, ctr, &ctr->trace_head,
-                              (s->use_rest ? c->refill_min_hyb | (c->refill_min_any_hyb << 16) | ((s->dev.arena_cull ? c->cull_min : c->leaf_min) << 7) | (c->exact_min << 23)
-                                           : c->refill_min | (c->refill_min_any << 16) | (c->leaf_min << 7)) | (c->steal ? 0x8000u : 0u) | shp_bit);
+                              (s->use_rest ? c->refill_min_hyb | (c->refill_min_any_hyb << 16) : c->refill_min | (c->refill_min_any << 16)) | (c->leaf_min << 7) | (c->steal ? 0x8000u : 0u) | shp_bit);
             if (tm) { int e = tm->end(); if (e) return e; }
         } else {
             if (tm) { int e = tm->begin(FAM_ANY); if (e) return e; }
@@ -1764,7 +1746,7 @@ extern "C" int cray_trace(cray_ctx* c, cray_scene* s, const cray_ray* rays, size
     const int g = grid_for(c, n, 8);
     Counters* ctr = c->counters;
     // the per-ray hook reads the records the context is pinned to (CRAY_HYBRID); a context that chooses per scene reads f64 here
-    s->hybrid_ok = hybrid_possible(c, s);
+    s->hybrid_ok = hybrid_possible(s);
     const int level = (c->hybrid > 0 && s->hybrid_ok) ? c->hybrid : 0;
     if ((e = ensure_hybrid(c, s, level))) return e;
     const bool shp = shapes_fit_lds(c, s->dev);   // the timed instantiations the frame loop would launch for this scene

@@ -59,9 +59,9 @@ constexpr uint32_t kTraceLdsShapes = 8;   // sphere + disk records (272 B each) 
 #else
 #define CRAY_CHILD_KEY child_key_code
 #endif
-//  HYB        : certified f32 culling (cray_math.h hyb_pair, tri_cull32): interior nodes are read as 64-B f32 records and leaf slots
-//               as f32 copies of their triangles; every decision the f32 enclosure cannot certify is retaken from the f64 record in
-//               a RESOLVE / EXACT step of the lane (cray_trace_step_hyb.inc).  Same hits, same counters.
+//  HYB        : certified f32 culling (cray_math.h hyb_pair): interior nodes are read as 64-B f32 records, every decision the f32
+//               enclosure cannot certify is retaken from the f64 record in a RESOLVE step of the lane (cray_trace_step_hyb.inc).
+//               Same hits, same counters.
 //  SHAPES_LDS : the scene's few sphere / disk records are staged in LDS by every block (the host picks this instantiation when they fit).
 //  TAIL       : the instantiation for SMALL mixed launches (fewer than Counters::tail_rays rays): such a launch is all drain — every
 //               lane holds one or two rays from the start and the launch lasts as long as its longest ray — so here idle lanes
@@ -131,10 +131,6 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PsArg ps_ar
     // (TAIL, below) has it as well, together with the certified split of closest-hit rays.
     static_assert(!TAIL || (MODE == kTraceMixed && !COUNT && HYB == 0), "the small-launch instantiation reads f64 records");
     static_assert(HYB == 0 || HYB == 1, "records: 0 f64, 1 certified f32 culling");
-#ifndef CRAY_CULL_HITS
-#define CRAY_CULL_HITS 1   // any-hit lanes end at a triangle whose f32 copy certifies the HIT (no distance is needed); 0: A/B builds
-#endif
-    [[maybe_unused]] constexpr bool kCullHits = MODE != kTraceClosest && CRAY_CULL_HITS != 0;
     constexpr bool STEAL = !COUNT && !HYB && (MODE == kTraceAny || TAIL);
     const bool steal_on = STEAL && (refill_min & 0x8000u) != 0;
     unsigned int age = 0, age_min = 0;   // TAIL: iterations this lane's segment has been walked / before it may hand parts out
@@ -247,8 +243,6 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PsArg ps_ar
     float t_lo = 0.f, t_hi = 0.f;
     uint32_t res = 0;
     bool resolve = false;
-    [[maybe_unused]] bool lexact = false;     // HYB: the slot `cur` names was not decided by its f32 copy — its f64 triangle is tested next
-    [[maybe_unused]] float d32x = 0.f, d32y = 0.f, d32z = 1.f;   // HYB: RN32 of ray.d (tri_cull32)
 
     if constexpr (HYB != 0) {
         // (how the loop is spelled: see the head of cray_trace_step.inc)
@@ -553,14 +547,13 @@ __global__ void __launch_bounds__(kBlock) k_make_inner32(const InnerNode* __rest
     o.ref0 = a.ref0; o.ref1 = a.ref1; o.axis = a.axis; o.pad_ = 0;
     out[i] = o;
 }
-// The arena of the certified f32 culling (cray_device.h): InnerNodeH records with references in the arena's encoding, then the
-// leaf slots' C and / or X records.  Derived on the device from the f64 layout.
-// (leaf_base / leaf_stride: where the records a leaf reference names start, and their stride)
-__host__ __device__ __forceinline__ uint32_t href_of(uint32_t ref, uint32_t leaf_base, uint32_t leaf_stride) {
+// The arena of the certified f32 culling (cray_device.h): InnerNodeH records with references in the arena's encoding; the leaf
+// slots behind them are copied from slots[] as they are.  Derived on the device from the f64 layout.
+__host__ __device__ __forceinline__ uint32_t href_of(uint32_t ref, uint32_t leaf_base) {
     if (!ref_is_leaf(ref)) return ref * (uint32_t)sizeof(InnerNodeH);
-    return (leaf_base + ref_leaf_first(ref) * leaf_stride) | kHLeaf | (ref_leaf_count(ref) - 1u);
+    return (leaf_base + ref_leaf_first(ref) * (uint32_t)sizeof(LeafSlot)) | kHLeaf | (ref_leaf_count(ref) - 1u);
 }
-__global__ void __launch_bounds__(kBlock) k_make_innerh(const InnerNode* __restrict__ in, uint32_t n, InnerNodeH* __restrict__ out, uint32_t leaf_base, uint32_t leaf_stride) {
+__global__ void __launch_bounds__(kBlock) k_make_innerh(const InnerNode* __restrict__ in, uint32_t n, InnerNodeH* __restrict__ out, uint32_t leaf_base) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const InnerNode a = in[i];
@@ -569,26 +562,8 @@ __global__ void __launch_bounds__(kBlock) k_make_innerh(const InnerNode* __restr
         o.lo[k][0] = f32_down(a.lo0[k]); o.hi[k][0] = f32_up(a.hi0[k]);
         o.lo[k][1] = f32_down(a.lo1[k]); o.hi[k][1] = f32_up(a.hi1[k]);
     }
-    o.ref0 = href_of(a.ref0, leaf_base, leaf_stride); o.ref1 = href_of(a.ref1, leaf_base, leaf_stride); o.axis = a.axis; o.pad_ = 0;
+    o.ref0 = href_of(a.ref0, leaf_base); o.ref1 = href_of(a.ref1, leaf_base); o.axis = a.axis; o.pad_ = 0;
     out[i] = o;
-}
-// (cull: the C region, or nullptr; exact / x_stride: the X region and its stride in bytes)
-__global__ void __launch_bounds__(kBlock) k_make_leafh(const LeafSlot* __restrict__ in, uint32_t n, LeafCullH* __restrict__ cull, char* __restrict__ exact, uint32_t x_stride) {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const LeafSlot a = in[i];
-    LeafExactH x;
-    for (int k = 0; k < 3; k++) { x.e1[k] = a.e1[k]; x.e2[k] = a.e2[k]; x.v0[k] = a.v0[k]; }
-    x.prim = a.prim; x.kind = a.kind;
-    *reinterpret_cast<LeafExactH*>(exact + (size_t)i * x_stride) = x;
-    if (cull) {
-        LeafCullH o;
-        for (int k = 0; k < 3; k++) { o.v0[k] = a.v0[k]; o.e1f[k] = (float)a.e1[k]; o.e2f[k] = (float)a.e2[k]; }
-        o.prim = a.prim; o.kind = a.kind;
-        o.e1m = f32_up(fmax(fmax(fabs(a.e1[0]), fabs(a.e1[1])), fabs(a.e1[2])));
-        o.e2m = f32_up(fmax(fmax(fabs(a.e2[0]), fabs(a.e2[1])), fabs(a.e2[2])));
-        cull[i] = o;
-    }
 }
 __global__ void __launch_bounds__(kBlock) k_make_slots32(const LeafSlot* __restrict__ in, uint32_t n, LeafSlot32* __restrict__ out) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
