@@ -3,7 +3,7 @@
 
 A "step" is one whole frame of the hot path: every path of the frame goes through
 raygen -> {trace_closest, shade, trace_any} x max_depth -> film, with the scene already resident in
-HBM.  At N GPUs the SAME frame is sharded by 64x64 pixel tile (tile % N == rank) and rank 0 gathers
+HBM.  At N GPUs the SAME frame is sharded by 64x64 pixel tile ((tx + s ty) % N == rank, cray_tile_pixels) and rank 0 gathers
 the Film tiles over RCCL (strong scaling, as the north star defines it) — through the C ABI
 (cray_comm_init / cray_scene_broadcast / cray_render_gather, include/cray.h): the path a Rust or C host
 takes, with no torch.distributed process group.  torch is used for the stream, the pinned host film and (N > 1)
@@ -485,7 +485,7 @@ def main():
             'data': 'synthetic',
             'config': {'workload': '%s, %s triangles, %dx%d, %d spp, depth %d'
                                    % (wl['label'], n_tris, W, H, wl['spp'], wl['max_depth']),
- 'parallelism': ('tile-shard x%d (32x32 tiles, tile %% N == rank); C ABI: cray_comm_init + %s + cray_render_gather (RCCL ncclSend/ncclRecv of Film tiles to rank 0)'
+ 'parallelism': ('tile-shard x%d (32x32 tiles, (tx + s ty) %% N == rank); C ABI: cray_comm_init + %s + cray_render_gather (RCCL ncclSend/ncclRecv of Film tiles to rank 0)'
                                        % (world, 'per-rank scene build' if args.replicate_host else 'cray_scene_broadcast (ncclBroadcast)')) if world > 1 else 'single GPU',
                        'seconds_per_frame': round(elapsed / args.steps, 4),
                        # the cold frame (rank 0): first cray_render of the process, pool allocation + record choice + tile probe included

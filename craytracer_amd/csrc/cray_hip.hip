@@ -177,7 +177,7 @@ int upload(cray_scene* s, const T* host, size_t n, const T** out) {
 
 // Bytes of path state per path of a pass: two live buffers (13 f64 + 4 words each), the shadow buffer (10 f64 + 2 words),
 // L (3 f64) and three queues.
-constexpr size_t kBytesPerPath = 2 * (13 * 8 + 4 * 4) + (10 * 8 + 2 * 4) + 3 * 8 + 3 * 4;
+constexpr size_t kBytesPerPath = 2 * (10 * 8 + 4 * 4) + 3 * 8 + (10 * 8 + 2 * 4) + 3 * 8 + 3 * 4;   // two live buffers, the hit record, the shadow buffer, L, three queues
 
 int ensure_state(cray_ctx* c, size_t capacity) {
     if (c->capacity >= capacity) return CRAY_OK;
@@ -193,7 +193,7 @@ int ensure_state(cray_ctx* c, size_t capacity) {
     const size_t slots = capacity + kShadeTile;
     int r;
     for (PathState* v : {&c->ps, &c->ps1}) {
-        double** live[] = {&v->ox, &v->oy, &v->oz, &v->dx, &v->dy, &v->dz, &v->br, &v->bg, &v->bb, &v->prev_pdf, &v->ht, &v->hu, &v->hv};
+        double** live[] = {&v->ox, &v->oy, &v->oz, &v->dx, &v->dy, &v->dz, &v->br, &v->bg, &v->bb, &v->prev_pdf};
         for (double** f : live)
             if ((r = alloc(slots * sizeof(double), (void**)f))) return r;
         if ((r = alloc(slots * 4, (void**)&v->hprim))) return r;
@@ -201,13 +201,18 @@ int ensure_state(cray_ctx* c, size_t capacity) {
         if ((r = alloc(slots * 4, (void**)&v->flags))) return r;
         if ((r = alloc(slots * 4, (void**)&v->p0))) return r;
     }
-    double** shared[] = {&c->ps.lr, &c->ps.lg, &c->ps.lb, &c->ps.sox, &c->ps.soy, &c->ps.soz, &c->ps.sdx, &c->ps.sdy, &c->ps.sdz, &c->ps.stmax,
+    // the hit record (distance, barycentrics) exists once: the traversal of bounce b writes it at the live slots of bounce b, k_shade(b)
+    // reads it there, and the traversal of bounce b + 1 — the next writer, at the slots of the OTHER live buffer — starts after
+    // k_shade(b) has ended.  (hprim stays per buffer: k_shade writes the next bounce's start primitive while other blocks still read
+    // this bounce's hit primitive.)  340 instead of 364 B per path.
+    double** shared[] = {&c->ps.ht, &c->ps.hu, &c->ps.hv, &c->ps.lr, &c->ps.lg, &c->ps.lb, &c->ps.sox, &c->ps.soy, &c->ps.soz, &c->ps.sdx, &c->ps.sdy, &c->ps.sdz, &c->ps.stmax,
                          &c->ps.cr, &c->ps.cg, &c->ps.cb};
     for (double** f : shared)
         if ((r = alloc(slots * sizeof(double), (void**)f))) return r;
     if ((r = alloc(slots * 4, (void**)&c->ps.sp0))) return r;
     if ((r = alloc(slots * 4, (void**)&c->ps.sprim))) return r;
     // the second view shares the shadow buffer and L
+    c->ps1.ht = c->ps.ht; c->ps1.hu = c->ps.hu; c->ps1.hv = c->ps.hv;
     c->ps1.lr = c->ps.lr; c->ps1.lg = c->ps.lg; c->ps1.lb = c->ps.lb;
     c->ps1.sox = c->ps.sox; c->ps1.soy = c->ps.soy; c->ps1.soz = c->ps.soz; c->ps1.sdx = c->ps.sdx; c->ps1.sdy = c->ps.sdy; c->ps1.sdz = c->ps.sdz;
     c->ps1.stmax = c->ps.stmax; c->ps1.cr = c->ps.cr; c->ps1.cg = c->ps.cg; c->ps1.cb = c->ps.cb; c->ps1.sp0 = c->ps.sp0; c->ps1.sprim = c->ps.sprim;
@@ -1008,19 +1013,40 @@ namespace {
 
 struct PassPlan { uint32_t px0, n_pix, s_lo, s_hi; };
 
-// pixels of the tiles this rank owns (tile_index % world == rank), tile by tile, row-major inside
-// a tile; tiles are numbered like generate_tiles (craytracer.rs:32-33): ty outer, tx inner.
+// The tile shard.  The reference hands its tiles to whichever worker thread is free (craytracer.rs:271-291); a static shard has to
+// spread the expensive image regions itself.  Rounds 2-4 gave tile t (numbered ty outer, tx inner, like generate_tiles,
+// craytracer.rs:32-33) to rank t % world: with tiles_x = 4 (mod 8) a rank then owns two of the eight column residues and nothing
+// of the others, and one rank of eight carried 3 % more of the dragon than the mean.  Round 5: tile (tx, ty) belongs to rank
+// (tx + s ty) % world with s the smallest stride >= 2 that is coprime with world (3 for eight ranks): in every row a rank owns
+// every world-th tile, and the phase walks through ALL residues from row to row.  walk_rank_tiles visits a rank's tiles row by
+// row, left to right — the order of its pixel list, of cray_film_pack and of what cray_render_gather sends.
+uint64_t shard_stride(uint64_t world) {
+    auto gcd = [](uint64_t a, uint64_t b) { while (b) { const uint64_t t = a % b; a = b; b = t; } return a; };
+    for (uint64_t s = 2; s + 1 < world; s++)
+        if (gcd(s, world) == 1) return s;
+    return world > 2 ? world - 1 : 1;
+}
+template <class F>
+void walk_rank_tiles(uint64_t tiles_x, uint64_t tiles_y, uint64_t rank, uint64_t world, F&& f) {
+    const uint64_t s = shard_stride(world);
+    for (uint64_t ty = 0; ty < tiles_y; ty++) {
+        const uint64_t phase = (s * ty) % world;
+        for (uint64_t tx = (rank + world - phase) % world; tx < tiles_x; tx += world) f(tx, ty);
+    }
+}
+
+// pixels of the tiles this rank owns, tile by tile, row-major inside a tile
 std::vector<uint32_t> rank_pixels(uint32_t W, uint32_t H, const cray_render_params& p) {
     std::vector<uint32_t> pix;
     // 64-bit tile arithmetic: a tile edge near 2^32 must not wrap `W + tw - 1` or `tx + tw` (one tile then covers the film)
     const uint64_t tw = p.tile_width, th = p.tile_height;
     const uint64_t tiles_x = (W + tw - 1) / tw, tiles_y = (H + th - 1) / th;
-    for (uint64_t t = p.rank; t < tiles_x * tiles_y; t += p.world_size) {
-        const uint64_t tx = (t % tiles_x) * tw, ty = (t / tiles_x) * th;
+    walk_rank_tiles(tiles_x, tiles_y, p.rank, p.world_size, [&](uint64_t txi, uint64_t tyi) {
+        const uint64_t tx = txi * tw, ty = tyi * th;
         const uint64_t x1 = tx + tw < W ? tx + tw : W, y1 = ty + th < H ? ty + th : H;
         for (uint64_t y = ty; y < y1; y++)
             for (uint64_t x = tx; x < x1; x++) pix.push_back((uint32_t)(y * W + x));
-    }
+    });
     return pix;
 }
 
@@ -1040,10 +1066,10 @@ extern "C" int cray_tile_pixels(uint32_t W, uint32_t H, uint32_t tw, uint32_t th
     if (!out) {   // the size query: tile areas summed, no map built
         const uint64_t tiles_x = ((uint64_t)W + tw - 1) / tw, tiles_y = ((uint64_t)H + th - 1) / th;
         uint64_t cnt = 0;
-        for (uint64_t t = rank; t < tiles_x * tiles_y; t += world) {
-            const uint64_t tx = (t % tiles_x) * tw, ty = (t / tiles_x) * th;
+        walk_rank_tiles(tiles_x, tiles_y, rank, world, [&](uint64_t txi, uint64_t tyi) {
+            const uint64_t tx = txi * tw, ty = tyi * th;
             cnt += ((tx + tw < W ? tx + tw : W) - tx) * ((ty + th < H ? ty + th : H) - ty);
-        }
+        });
         *n_pixels = cnt;
         return CRAY_OK;
     }
@@ -1422,13 +1448,13 @@ int ensure_tile_order(cray_ctx* c, cray_scene* s, const cray_render_params& prm,
         const uint64_t tw = prm.tile_width, th = prm.tile_height;
         const uint64_t tiles_x = (W + tw - 1) / tw, tiles_y = (H + th - 1) / th;
         uint64_t at = 0;
-        for (uint64_t t = prm.rank; t < tiles_x * tiles_y; t += prm.world_size) {
-            const uint64_t tx = (t % tiles_x) * tw, ty = (t / tiles_x) * th;
+        walk_rank_tiles(tiles_x, tiles_y, prm.rank, prm.world_size, [&](uint64_t txi, uint64_t tyi) {
+            const uint64_t tx = txi * tw, ty = tyi * th;
             const uint64_t x1 = tx + tw < W ? tx + tw : W, y1 = ty + th < H ? ty + th : H;
             rect.push_back((uint32_t)tx); rect.push_back((uint32_t)ty); rect.push_back((uint32_t)(x1 - tx)); rect.push_back((uint32_t)(y1 - ty));
             start.push_back((uint32_t)at);
             at += (x1 - tx) * (y1 - ty);
-        }
+        });
         const size_t n_tiles = start.size();
         if (n_tiles < 64 || at != c->pix_count) return CRAY_OK;
         start.push_back((uint32_t)at);

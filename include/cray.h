@@ -104,7 +104,7 @@ typedef struct {
     uint32_t tile_width;        /* 64  (craytracer.rs:232) */
     uint32_t tile_height;       /* 64  (craytracer.rs:233) */
     uint32_t sample_batch;      /* 8   (craytracer.rs:234): f64 sum of a batch -> f32 add into the film */
-    uint32_t rank, world_size;  /* this ctx renders tiles with tile_index % world_size == rank;
+    uint32_t rank, world_size;  /* this ctx renders the tiles (tx, ty) with (tx + s ty) % world_size == rank, s = the smallest stride >= 2 coprime with world_size (cray_tile_pixels);
                                    pixels of other tiles are left 0 in out_rgb. (0,1) = whole film */
     uint32_t sample_begin, sample_end; /* render samples [begin,end); (0,0) = all. Always divides by num_samples */
     uint32_t out_is_device;     /* 0: out_rgb is host memory; 1: device memory on the ctx's GPU */
@@ -233,7 +233,7 @@ void cray_scene_build_stats(const cray_scene* scene, cray_bvh_build_stats* out);
  * Replaces the reference's merge point, the shared `Mutex<Vec<f32>>` every worker thread adds its tile into
  * (src/bin/craytracer.rs:245, workers :271-291, merge :182-188), for workers that are GPUs of one node:
  * one process (or host thread) per GPU, one cray_ctx each.  Rank r renders the 64x64 tiles with
- * tile_index % world == r (tiles numbered like generate_tiles, :22-43) for ALL samples, so every pixel is
+ * (tx + s ty) % world == r (tiles (tx, ty) of generate_tiles' grid, :22-43; s as in cray_render_params.rank) for ALL samples, so every pixel is
  * accumulated on one GPU in the single-GPU order and the assembled film is bit-identical to a 1-GPU render.
  * The only exchange is ONE gather of packed tiles to rank 0 after rendering (grouped ncclSend / ncclRecv:
  * W*H*12/world bytes per rank over the direct xGMI link to rank 0); nothing is communicated while rendering.
@@ -300,7 +300,7 @@ int cray_film_unpack(cray_ctx* ctx, uint32_t width, uint32_t height, uint32_t ti
                      uint32_t world_size, const float* gathered, float* out);
 
 /* The shard map on its own (host only, no context, no GPU): the linear pixel indices y*W + x of the tiles `rank` owns, tile by
- * tile (tiles numbered like generate_tiles, craytracer.rs:22-43; tile_index % world_size == rank), row-major inside a tile —
+ * tile (the tiles (tx, ty) of generate_tiles' grid, craytracer.rs:22-43, with (tx + s ty) % world_size == rank, row by row; s = the smallest stride >= 2 coprime with world_size, world_size - 1 when there is none, 1 for one or two ranks), row-major inside a tile —
  * the order of cray_film_pack's output and of the buffer cray_render_gather sends.  out may be NULL to query *n_pixels. */
 int cray_tile_pixels(uint32_t width, uint32_t height, uint32_t tile_width, uint32_t tile_height, uint32_t rank, uint32_t world_size,
                      uint32_t* out, uint64_t capacity, uint64_t* n_pixels);

@@ -55,6 +55,30 @@ def test_the_abi_s_tile_map_is_the_reference_s():
             pass
 
 
+def test_a_rank_s_tiles_walk_through_every_column_residue():
+    """Round 5: tile (tx, ty) belongs to rank (tx + s ty) % world, s coprime with world — in every row a rank owns every world-th tile
+    and over `world` consecutive rows its first tile starts at every residue once (with `t % world` and tiles_x = 4 mod 8 a rank of
+    eight owned two column residues and none of the others: one rank carried 3 % more of the frame than the mean)."""
+    for world in (2, 3, 4, 5, 6, 7, 8, 9, 16):
+        s = cdist.shard_stride(world)
+        assert np.gcd(s, world) == 1 and 1 <= s < max(world, 2)
+        W, H, t = 32 * world * 2 + 5, 32 * world * 3, 32
+        tiles_x = (W + t - 1) // t
+        for rank in (0, world - 1):
+            pix = backend.tile_pixels(W, H, rank, world, tile=(t, t))
+            assert np.array_equal(pix, cdist.rank_pixels(W, H, rank, world, t, t))
+            ty, tx = (pix // W) // t, (pix % W) // t
+            first = {}
+            for y, x in zip(ty.tolist(), tx.tolist()):
+                first.setdefault(y, x)                      # pixels come tile by tile, rows of tiles top to bottom, left to right
+                assert (x + s * y) % world == rank
+            assert len(first) == H // t
+            phases = [first[y] for y in range(world)]
+            assert sorted(phases) == list(range(world)), (world, phases)      # every residue once in `world` rows
+    sizes = [len(backend.tile_pixels(1920, 1080, r, 8, tile=(32, 32))) for r in range(8)]
+    assert sum(sizes) == 1920 * 1080 and max(sizes) - min(sizes) <= 34 * 32 * 32   # at most one tile per row of tiles apart
+
+
 def _worker(rank, world, port, W, H, out_path):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """configs[4] (3840x2160, 1024 spp: the 8-GPU configuration of BASELINE.json) rehearsed on ONE GPU: the whole frame once and rank
-`--rank`'s eighth of it (32x32 shard tiles, tile % 8 == rank), both timed after a warm-up that absorbs the path pool's allocation.
+`--rank`'s eighth of it (32x32 shard tiles, (tx + 3 ty) % 8 == rank), both timed after a warm-up that absorbs the path pool's allocation.
 One-GPU rehearsal: no gather, no RCCL.   python tools/eighth_4k.py [--rank 3] [--whole 1]"""
 import argparse
 import json
