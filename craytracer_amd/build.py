@@ -11,7 +11,7 @@ import subprocess
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 SO = os.path.join(CSRC, 'libcray_hip.so')
 SOURCES = ['cray_hip.hip', 'cray_host.cpp', 'cray_cry.cpp', 'cray_io.cpp', 'cray_image.cpp']
-HEADERS = ['cray_trace_step.inc', 'cray_trace_step_hyb.inc', 'cray_math.h', 'cray_device.h', 'cray_shading.h', 'cray_kernels.h', 'cray_bvh_build.h', 'sobol_rev_vectors.h',
+HEADERS = ['cray_trace_step.inc', 'cray_trace_step_hyb.inc', 'cray_cull_check.h', 'cray_math.h', 'cray_device.h', 'cray_shading.h', 'cray_kernels.h', 'cray_bvh_build.h', 'sobol_rev_vectors.h',
            '../../include/cray_io.h',
            '../../include/cray.h', '../../include/cray_host.h', '../../include/cray_scene_desc.h', '../../include/cray_cry.h']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared', '-Wall',

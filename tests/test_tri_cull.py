@@ -139,3 +139,35 @@ def test_millimetre_triangles_far_from_the_origin():
     bad, counts = _run(v0, e1, e2, o, d, tmax)
     assert bad == 0
     assert counts[0] < 0.03 * n, counts   # what stays with the exact test
+
+
+def test_the_check_fails_when_the_error_constant_is_too_small(tmp_path):
+    """Mutation check: the same host code compiled with K = 0.5 u instead of 47 u (the f32 side then trusts its numerators far more
+    than their rounding allows) must be caught by these very inputs — certified answers that contradict the f64 test."""
+    import ctypes as C
+    import os
+    import shutil
+    import subprocess
+    clang = shutil.which('clang++') or '/opt/rocm/lib/llvm/bin/clang++'
+    if not os.path.exists(clang):
+        import pytest
+        pytest.skip('no clang++ to build the mutated check with')
+    src = tmp_path / 'mut.cpp'
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'craytracer_amd', 'csrc')
+    src.write_text('#include "cray_cull_check.h"\nextern "C" uint64_t check(const double* a, const double* b, const double* c, const double* d, const double* e, '
+                   'const double* f, uint64_t n, uint64_t* k) { return cray::tri_cull_violations(a, b, c, d, e, f, n, k); }\n')
+    so = str(tmp_path / 'mut.so')
+    subprocess.check_call([clang, '-O2', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared', '-DCRAY_CULL_K_UNITS=0.5f', '-I', csrc, '-o', so, str(src)])
+    L = C.CDLL(so)
+    L.check.restype = C.c_uint64
+    L.check.argtypes = [C.c_void_p] * 6 + [C.c_uint64, C.c_void_p]
+    rng = np.random.default_rng(22)
+    n = 200_000
+    v0, e1, e2 = _tris(rng, n, -1, 2, -3, 0)
+    eps = rng.choice([1e-9, -1e-9, 6e-8, -6e-8, 1e-6, -1e-6], n)
+    bu = np.where(rng.random(n) < 0.5, eps, 1.0 + eps)
+    bv = rng.uniform(0.0, 0.5, n)
+    o, d = _aim(rng, v0, e1, e2, bu, bv, 10.0 ** rng.uniform(-2, 2, n))
+    arrs = [np.ascontiguousarray(x, dtype=np.float64) for x in (v0, e1, e2, o, d, np.full(n, np.inf))]
+    assert L.check(*[a.ctypes.data for a in arrs], n, None) > 0                      # the mutant is caught
+    assert _run(*arrs)[0] == 0                                                         # the real constant is not
