@@ -154,6 +154,7 @@ struct cray_scene {
     // what the CURRENT call reads (counting frames and the f32 fast mode read f64 records whatever was chosen).
     int use_b0 = 0, use_rest = 0;
     int chosen_b0 = -1, chosen_rest = -1;   // -1: not chosen yet
+    bool needs_deep = false;       // a frame of this scene overflowed LDS + scratch: its launches run in the instantiations with the third stack level
     double tune_ms[2][2] = {{0.0, 0.0}, {0.0, 0.0}};   // [records][kind]: best time of the probe passes' bounce-0 launch / other traversal launches
     double probe_ms = 0.0;         // wall time the probe passes took (once per scene)
 };
@@ -1135,7 +1136,7 @@ int ensure_hybrid(cray_ctx* c, cray_scene* s, int level) {
 int choose_trace_records(cray_ctx* c, cray_scene* s, bool counting, size_t n_paths, bool* want_probe) {
     if (want_probe) *want_probe = false;
     s->hybrid_ok = hybrid_possible(s);
-    if (!s->hybrid_ok) { s->use_b0 = s->use_rest = 0; return CRAY_OK; }
+    if (!s->hybrid_ok || s->needs_deep) { s->use_b0 = s->use_rest = 0; return CRAY_OK; }   // (the instantiations with the third stack level read f64 records)
     if (c->hybrid >= 0) {
         s->use_b0 = s->use_rest = c->hybrid;
     } else if (counting) {
@@ -1208,9 +1209,11 @@ struct ShadeLaunch<kNumShadeVariants> {
 // The traversal launches: which records they read (v: 0 f64, 1 certified f32 culling) and whether the scene's few
 // sphere / disk records are staged in LDS (shp: those instantiations get bit 14 of refill_min) pick the instantiation.
 // Counting launches exist for v 0 and 1 only; the f64 any-hit launch keeps its LDS for the work sharing.
+// deep: the context has the third stack level (a frame overflowed LDS + scratch): the instantiations that carry it, on f64 records.
 template <bool ANY, bool COUNT, class... A>
-void launch_trace(int v, bool shp, int grid, hipStream_t st, A... a) {
+void launch_trace(int v, bool shp, bool deep, int grid, hipStream_t st, A... a) {
     const dim3 g(grid), b(kBlock);
+    if (deep) { hipLaunchKernelGGL((k_trace<ANY, COUNT, 0, false, true>), g, b, 0, st, a...); return; }
     if constexpr (COUNT) {
         if (v == 1) hipLaunchKernelGGL((k_trace<ANY, true, 1>), g, b, 0, st, a...);
         else hipLaunchKernelGGL((k_trace<ANY, true, 0>), g, b, 0, st, a...);
@@ -1222,8 +1225,9 @@ void launch_trace(int v, bool shp, int grid, hipStream_t st, A... a) {
     }
 }
 template <class... A>
-void launch_mixed(int v, bool shp, bool tail, int grid, hipStream_t st, A... a) {
+void launch_mixed(int v, bool shp, bool tail, bool deep, int grid, hipStream_t st, A... a) {
     const dim3 g(grid), b(kBlock);
+    if (deep) { hipLaunchKernelGGL((k_trace_mixed<0, false, false, true>), g, b, 0, st, a...); return; }
     // a mixed launch is launched twice when the small-launch instantiation is on (Counters::tail_rays != 0): each of the two
     // returns at once unless the launch has its size — the host does not know the queue lengths
 #ifdef CRAY_WITH_EXPERIMENTS
@@ -1264,7 +1268,8 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
     // kind keeps its own launch so that the counters stay per kind.
     const bool mixed = !count && c->mix_trace;
     const bool fast = prm.precision == CRAY_PRECISION_F32_TRAVERSAL;   // check_render_args refuses it together with counting
-    const bool shp = shapes_fit_lds(c, d);
+    const bool deep = s->needs_deep && c->deep_depth != 0;   // this scene needs the third stack level: its instantiations (f64 records) trace the pass
+    const bool shp = shapes_fit_lds(c, d) && !deep;
     const unsigned int shp_bit = (shp ? 0x4000u : 0u) | (c->tail_seg ? 0x2000u : 0u);   // + whether small launches split segments: both ride in refill_min
     const unsigned int trace_all = prm.count_traversal == 1 ? 1u : 0u;  // 2 = count, but keep skipping zero-term shadow rays
     for (uint32_t b = 0; b < d.max_depth; b++) {
@@ -1283,9 +1288,9 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
             HIP_TRY(hipMemsetAsync(&ctr->trace_head, 0, sizeof(unsigned int), st));
             if (tm) { int e = tm->begin(FAM_CLOSEST); if (e) return e; }
             const int v_closest = b == 0 ? s->use_b0 : s->use_rest;
-            if (count) launch_trace<false, true>(v_closest, shp, g_trace, st, d, ps_b, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
+            if (count) launch_trace<false, true>(v_closest, shp, deep, g_trace, st, d, ps_b, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
             else if (fast) hipLaunchKernelGGL((k_trace32<kTraceClosest>), dim3(g_trace32), dim3(kBlock), 0, st, d, ps_b, q, nq, n_paths, (const uint32_t*)nullptr, (const unsigned int*)nullptr, ctr, &ctr->trace_head, b == 0 ? c->refill_min_b0 : c->refill_min, b == 0 ? 1u : 0u);
-            else launch_trace<false, false>(v_closest, shp, g_trace, st, d, ps_b, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, (b == 0 ? c->refill_min_b0 : c->refill_min) | shp_bit);
+            else launch_trace<false, false>(v_closest, shp, deep, g_trace, st, d, ps_b, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, (b == 0 ? c->refill_min_b0 : c->refill_min) | shp_bit);
             if (tm) { int e = tm->end(); if (e) return e; }
         }
 
@@ -1302,18 +1307,18 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
             if (tm) { int e = tm->begin(FAM_MIXED); if (e) return e; }
             if (fast) hipLaunchKernelGGL((k_trace32<kTraceMixed>), dim3(g_trace32), dim3(kBlock), 0, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, 0u,
                                          (const uint32_t*)q_next, (const unsigned int*)n_next, ctr, &ctr->trace_head, c->refill_min, 0u);
-            else launch_mixed(s->use_rest, shp, c->tail_res != nullptr, g_trace, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, (const uint32_t*)q_next,
+            else launch_mixed(s->use_rest, shp, c->tail_res != nullptr, deep, g_trace, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, (const uint32_t*)q_next,
                               (const unsigned int*)n_next, ctr, &ctr->trace_head,
                               (s->use_rest ? c->refill_min_hyb | (c->refill_min_any_hyb << 16) : c->refill_min | (c->refill_min_any << 16)) | (c->leaf_min << 7) | (c->steal ? 0x8000u : 0u) | shp_bit);
             if (tm) { int e = tm->end(); if (e) return e; }
         } else {
             if (tm) { int e = tm->begin(FAM_ANY); if (e) return e; }
-            if (count) launch_trace<true, true>(s->use_rest, shp, g_trace, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
+            if (count) launch_trace<true, true>(s->use_rest, shp, deep, g_trace, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
             else if (fast) hipLaunchKernelGGL((k_trace32<kTraceAny>), dim3(g_trace32), dim3(kBlock), 0, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, 0u,
                                               (const uint32_t*)nullptr, (const unsigned int*)nullptr, ctr, &ctr->trace_head, c->refill_min, 0u);
             // (the any-hit launch of the last bounce is all drain: the f64 instantiation, which shares work between lanes, beats
             // the f32 culling there — 0.22 against 0.47 ms at an eighth of configs[2])
-            else launch_trace<true, false>((s->use_rest == 1 && c->steal) ? 0 : s->use_rest, shp, g_trace, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min_any | (c->steal ? 0x8000u : 0u) | shp_bit);
+            else launch_trace<true, false>((s->use_rest == 1 && c->steal) ? 0 : s->use_rest, shp, deep, g_trace, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min_any | (c->steal ? 0x8000u : 0u) | shp_bit);
             if (tm) { int e = tm->end(); if (e) return e; }
         }
         if (c->log_queues) {   // diagnostics only: a host round trip per bounce
@@ -1630,9 +1635,11 @@ int render_local(cray_ctx* c, cray_scene* s, const cray_render_params* prm, cray
         }
         if (!h.stack_overflow) return CRAY_OK;
         // a ray needed more pending nodes than the traversal stack holds: its result is not the reference's
-        if (c->deep_depth == 0 && attempt == 0) {
-            // first time on this context: add the third stack level (HBM) and render the frame again
+        if (!s->needs_deep && attempt == 0) {
+            // first time for this scene: add the third stack level (HBM, once per context) and render the frame again in the
+            // instantiations that carry it
             if ((e = ensure_deep(c))) return e;
+            s->needs_deep = true;
             continue;
         }
         set_last_error("BVH deeper than the %u-entry traversal stack: %llu lane(s) overflowed; the film is not valid",
@@ -1785,11 +1792,11 @@ extern "C" int cray_trace(cray_ctx* c, cray_scene* s, const cray_ray* rays, size
         HIP_TRY(hipMemcpy(c->shadow_queue, iota.data(), n * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(&ctr->n_shadow, &cnt, sizeof(cnt), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(&ctr->n_active0, &cnt, sizeof(cnt), hipMemcpyHostToDevice));
-        launch_mixed(level, shp, c->tail_res != nullptr, g, c->stream, s->dev, ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, (const uint32_t*)nullptr,
+        launch_mixed(level, shp, c->tail_res != nullptr, s->needs_deep && c->deep_depth != 0, g, c->stream, s->dev, ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, (const uint32_t*)nullptr,
                      (const unsigned int*)&ctr->n_active0, ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16) | (c->steal ? 0x8000u : 0u) | (shp ? 0x4000u : 0u) | (c->tail_seg ? 0x2000u : 0u));
     } else {
 #define CRAY_TRACE_GO(ANY_, COUNT_, TMAX_)                                                                                       \
-    launch_trace<ANY_, COUNT_>(level, shp, g, c->stream, s->dev, ps, (const uint32_t*)nullptr, (const unsigned int*)nullptr, (uint32_t)n, TMAX_, ctr, \
+    launch_trace<ANY_, COUNT_>(level, shp, s->needs_deep && c->deep_depth != 0, g, c->stream, s->dev, ps, (const uint32_t*)nullptr, (const unsigned int*)nullptr, (uint32_t)n, TMAX_, ctr, \
                                &ctr->trace_head, c->refill_min | (c->steal ? 0x8000u : 0u) | (shp ? 0x4000u : 0u))
         // closest hit with caller-supplied tmax: rays whose tmax is finite go through the same kernel via stmax
         if (mode == CRAY_TRACE_ANY) CRAY_TRACE_GO(true, true, (const double*)nullptr);
@@ -1820,8 +1827,9 @@ extern "C" int cray_trace(cray_ctx* c, cray_scene* s, const cray_ray* rays, size
     Counters h;
     HIP_TRY(hipMemcpy(&h, c->counters, sizeof(h), hipMemcpyDeviceToHost));
     if (h.stack_overflow) {
-        if (c->deep_depth == 0) {
+        if (!s->needs_deep) {
             if ((e = ensure_deep(c))) return e;
+            s->needs_deep = true;
             return cray_trace(c, s, rays, n, hits, mode, stats);
         }
         set_last_error("BVH deeper than the %u-entry traversal stack", (unsigned)kStackDepth + c->deep_depth);

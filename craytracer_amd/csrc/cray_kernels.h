@@ -107,7 +107,7 @@ __global__ void k_kernarg_check(DevScene sc, PathState ps, PathState po, uint32_
     if (threadIdx.x == 0 && blockIdx.x == 0) *bad = e;
 }
 
-template <int MODE, bool COUNT, int HYB, bool SHAPES_LDS = false, bool TAIL = false>
+template <int MODE, bool COUNT, int HYB, bool SHAPES_LDS = false, bool TAIL = false, bool DEEP = false>
 __device__ __forceinline__ void trace_body(const DevScene& sc, const PsArg ps_arg, const uint32_t* __restrict__ queue, const uint32_t n_first,
                                            const uint32_t* __restrict__ queue_b, const uint32_t n_b, const double* __restrict__ closest_tmax,
                                            Counters* ctr, unsigned int* work_head, unsigned int refill_min) {
@@ -131,6 +131,7 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PsArg ps_ar
     // (TAIL, below) has it as well, together with the certified split of closest-hit rays.
     static_assert(!TAIL || (MODE == kTraceMixed && !COUNT && HYB == 0), "the small-launch instantiation reads f64 records");
     static_assert(HYB == 0 || HYB == 1, "records: 0 f64, 1 certified f32 culling");
+    static_assert(!DEEP || (HYB == 0 && !SHAPES_LDS && !TAIL), "the instantiations with the third stack level read f64 records");
     constexpr bool STEAL = !COUNT && !HYB && (MODE == kTraceAny || TAIL);
     const bool steal_on = STEAL && (refill_min & 0x8000u) != 0;
     unsigned int age = 0, age_min = 0;   // TAIL: iterations this lane's segment has been walked / before it may hand parts out
@@ -193,15 +194,25 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PsArg ps_ar
     uint32_t tfl = 0;           // TAIL: kTf* flags of this lane
     unsigned int n_help = 0, n_again = 0;   // TAIL: parts of segments this lane handed to helpers / rays it walked again (cray_stats.tail_split)
     // (r_: reference, w0_ / w1_: the two payload words)
+    // (third level, DEEP instantiations only: the code of a level that is almost never there cost the loop 1.5 % by being there,
+    // profiles/r05_experiments.md — the runtime launches those after a frame reported an overflow, and they read the f64 records)
+#define CRAY_DEEP_PUSH(r_, w0_, w1_)                                                       \
+        else if (DEEP && sp < kStackDepth + (int)ctr->deep_depth) {                        \
+            const size_t at_ = (size_t)(sp - kStackDepth) * ((size_t)gridDim.x * kBlock) + (size_t)blockIdx.x * kBlock + tid; \
+            ctr->deep_ref[at_] = (r_);                                                     \
+            ctr->deep_key[at_] = __hiloint2double((int)(w1_), (int)(w0_)); sp++;           \
+        } else overflow = 1;
+#define CRAY_DEEP_POP(r_, w0_, w1_)                                                        \
+        else if (DEEP) {                                                                   \
+            const size_t at_ = (size_t)(sp - kStackDepth) * ((size_t)gridDim.x * kBlock) + (size_t)blockIdx.x * kBlock + tid; \
+            const double dk_ = ctr->deep_key[at_];                                         \
+            r_ = ctr->deep_ref[at_]; w0_ = (uint32_t)__double2loint(dk_); w1_ = (uint32_t)__double2hiint(dk_);  \
+        } else { r_ = 0u; w0_ = 0u; w1_ = 0u; }
 #define CRAY_PUSH_W(r_, w0_, w1_)                                                          \
     do {                                                                                   \
         if (sp < kLdsStack) { CRAY_LDS_REF(sp, tid) = (r_); CRAY_LDS_W0(sp, tid) = (w0_); CRAY_LDS_W1(sp, tid) = (w1_); sp++; } \
         else if (sp < kStackDepth) { sst[(sp - kLdsStack) * 3] = (r_); sst[(sp - kLdsStack) * 3 + 1] = (w0_); sst[(sp - kLdsStack) * 3 + 2] = (w1_); sp++; }      \
-        else if (sp < kStackDepth + (int)ctr->deep_depth) {                                \
-            const size_t at_ = (size_t)(sp - kStackDepth) * ((size_t)gridDim.x * kBlock) + (size_t)blockIdx.x * kBlock + tid; \
-            ctr->deep_ref[at_] = (r_);                                                     \
-            ctr->deep_key[at_] = __hiloint2double((int)(w1_), (int)(w0_)); sp++;           \
-        } else overflow = 1;                                                               \
+        CRAY_DEEP_PUSH(r_, w0_, w1_)                                                       \
     } while (0)
 #define CRAY_PUSH(r_, k_) CRAY_PUSH_W(r_, (uint32_t)__double2loint(k_), (uint32_t)__double2hiint(k_))
 #define CRAY_PUSH_H(r_, kc_, par_) CRAY_PUSH_W(r_, __float_as_uint(kc_), (par_))
@@ -209,11 +220,7 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PsArg ps_ar
     do {                                                                                   \
         if (sp < kLdsStack) { r_ = CRAY_LDS_REF(sp, tid); w0_ = CRAY_LDS_W0(sp, tid); w1_ = CRAY_LDS_W1(sp, tid); } \
         else if (sp < kStackDepth) { r_ = sst[(sp - kLdsStack) * 3]; w0_ = sst[(sp - kLdsStack) * 3 + 1]; w1_ = sst[(sp - kLdsStack) * 3 + 2]; }               \
-        else {                                                                             \
-            const size_t at_ = (size_t)(sp - kStackDepth) * ((size_t)gridDim.x * kBlock) + (size_t)blockIdx.x * kBlock + tid; \
-            const double dk_ = ctr->deep_key[at_];                                         \
-            r_ = ctr->deep_ref[at_]; w0_ = (uint32_t)__double2loint(dk_); w1_ = (uint32_t)__double2hiint(dk_);  \
-        }                                                                                  \
+        CRAY_DEEP_POP(r_, w0_, w1_)                                                        \
     } while (0)
     int sp = 0;
     bool active = false, exhausted = false;
@@ -293,26 +300,28 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PsArg ps_ar
 #undef CRAY_PUSH_H
 #undef CRAY_PUSH_W
 #undef CRAY_POP_W
+#undef CRAY_DEEP_PUSH
+#undef CRAY_DEEP_POP
 #undef CRAY_LDS_REF
 #undef CRAY_LDS_W0
 #undef CRAY_LDS_W1
 #undef CRAY_ANY_LANE
 }
 
-template <bool ANY, bool COUNT, int HYB, bool SHAPES_LDS = false>
+template <bool ANY, bool COUNT, int HYB, bool SHAPES_LDS = false, bool DEEP = false>
 __global__ void CRAY_TRACE_EU __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace(DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
                                                   const unsigned int* __restrict__ n_ptr, uint32_t n_fixed,
                                                   const double* __restrict__ closest_tmax, Counters* ctr, unsigned int* work_head, unsigned int refill_min) {
-    trace_body<ANY ? kTraceAny : kTraceClosest, COUNT, HYB, SHAPES_LDS>(sc, ps_kernarg(), queue, n_ptr ? *n_ptr : n_fixed, nullptr, 0u, closest_tmax, ctr, work_head, refill_min);
+    trace_body<ANY ? kTraceAny : kTraceClosest, COUNT, HYB, SHAPES_LDS, false, DEEP>(sc, ps_kernarg(), queue, n_ptr ? *n_ptr : n_fixed, nullptr, 0u, closest_tmax, ctr, work_head, refill_min);
 }
 
 // shadow rays of one bounce (any_queue) + path segments of the next (closest_queue) in one persistent launch
-template <int HYB, bool SHAPES_LDS = false, bool TAIL = false>
+template <int HYB, bool SHAPES_LDS = false, bool TAIL = false, bool DEEP = false>
 __global__ void CRAY_TRACE_EU __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace_mixed(DevScene sc, PathState ps, const uint32_t* __restrict__ any_queue,
                                                   const unsigned int* __restrict__ n_any_ptr, const uint32_t* __restrict__ closest_queue,
                                                   const unsigned int* __restrict__ n_closest_ptr, Counters* ctr, unsigned int* work_head,
                                                   unsigned int refill_min) {
-    trace_body<kTraceMixed, false, HYB, SHAPES_LDS, TAIL>(sc, ps_kernarg(), any_queue, *n_any_ptr, closest_queue, *n_closest_ptr, nullptr, ctr, work_head, refill_min);
+    trace_body<kTraceMixed, false, HYB, SHAPES_LDS, TAIL, DEEP>(sc, ps_kernarg(), any_queue, *n_any_ptr, closest_queue, *n_closest_ptr, nullptr, ctr, work_head, refill_min);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
