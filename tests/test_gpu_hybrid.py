@@ -114,6 +114,11 @@ def test_a_context_that_chooses_its_records_per_scene_renders_the_same_film():
         seen.append(st['trace_records'])
     assert (seen[0] & 15) in (0, 1) and (seen[0] >> 4) in (0, 1), seen      # the first frame already reads the chosen records
     assert seen[1] == seen[0] and seen[2] == seen[0], seen                   # ... and so does every later one
+    info = dev.records_info()                                                # cray_scene_records_info: the choice and what it cost
+    assert info['chosen'] == (seen[0] & 15, seen[0] >> 4) and 0.0 < info['probe_ms'] < 2000.0
+    assert all(v > 0.0 for k in info['probe_kernel_ms'].values() for v in k.values())
+    pool_bytes, pool_paths = ctx.pool_info()                                 # cray_ctx_pool_info: the pool the first frame allocated
+    assert pool_paths >= 512 * 288 * 16 and pool_bytes == pool_paths * 340
     fc, stc = dev.render(seed=2, count_traversal=True)                       # counting frames always read f64 records
     assert stc['trace_records'] == 0 and np.array_equal(fc, ref)
     f, st = dev.render(seed=2)                                               # ... and leave the scene's choice alone
@@ -122,6 +127,7 @@ def test_a_context_that_chooses_its_records_per_scene_renders_the_same_film():
     small = ctx.upload(backend.HostScene(dict(small_scenes())['cornell']))
     for _ in range(3):
         assert small.render(seed=1)[1]['trace_records'] == 0
+    assert small.records_info()['chosen'] == (-1, -1) and small.records_info()['probe_ms'] == 0.0
     small.close()
     ctx.close()
 
