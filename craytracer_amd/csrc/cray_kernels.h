@@ -252,6 +252,7 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PsArg ps_ar
     bool resolve = false;
 
     if constexpr (HYB != 0) {
+        unsigned long long active_m = 0ull, resolve_m = 0ull;   // the mixed / any-hit launches' `active` and `resolve` between iterations (step file)
         // (how the loop is spelled: see the head of cray_trace_step.inc)
         auto step = [&]() __attribute__((always_inline)) -> bool {
 #define CRAY_STEP_BREAK return true
