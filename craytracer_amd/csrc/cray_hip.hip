@@ -1783,6 +1783,9 @@ extern "C" int cray_trace(cray_ctx* c, cray_scene* s, const cray_ray* rays, size
     const int level = (c->hybrid > 0 && s->hybrid_ok) ? c->hybrid : 0;
     if ((e = ensure_hybrid(c, s, level))) return e;
     const bool shp = shapes_fit_lds(c, s->dev);   // the timed instantiations the frame loop would launch for this scene
+    hipEvent_t ev_[2] = {nullptr, nullptr};   // the launch's time for `stats` (trace_mixed_ms / trace_any_ms / trace_closest_ms)
+    if (stats) { HIP_TRY(hipEventCreate(&ev_[0])); HIP_TRY(hipEventCreate(&ev_[1])); }
+    struct EvFree { hipEvent_t* e; ~EvFree() { for (int i = 0; i < 2; i++) if (e[i]) (void)hipEventDestroy(e[i]); } } ev_free_{ev_};
     if (mixed) {
         // k_trace_mixed as the frame loop launches it: positions [0, n) of the virtual queue are the shadow rays of paths
         // 0..n-1 (an identity queue), positions [n, 2n) the path segments of the same paths (tmax = +inf, like Ray::new)
@@ -1792,6 +1795,7 @@ extern "C" int cray_trace(cray_ctx* c, cray_scene* s, const cray_ray* rays, size
         HIP_TRY(hipMemcpy(c->shadow_queue, iota.data(), n * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(&ctr->n_shadow, &cnt, sizeof(cnt), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(&ctr->n_active0, &cnt, sizeof(cnt), hipMemcpyHostToDevice));
+        if (stats) HIP_TRY(hipEventRecord(ev_[0], c->stream));
         launch_mixed(level, shp, c->tail_res != nullptr, s->needs_deep && c->deep_depth != 0, g, c->stream, s->dev, ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, (const uint32_t*)nullptr,
                      (const unsigned int*)&ctr->n_active0, ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16) | (c->steal ? 0x8000u : 0u) | (shp ? 0x4000u : 0u) | (c->tail_seg ? 0x2000u : 0u));
     } else {
@@ -1799,12 +1803,14 @@ extern "C" int cray_trace(cray_ctx* c, cray_scene* s, const cray_ray* rays, size
     launch_trace<ANY_, COUNT_>(level, shp, s->needs_deep && c->deep_depth != 0, g, c->stream, s->dev, ps, (const uint32_t*)nullptr, (const unsigned int*)nullptr, (uint32_t)n, TMAX_, ctr, \
                                &ctr->trace_head, c->refill_min | (c->steal ? 0x8000u : 0u) | (shp ? 0x4000u : 0u))
         // closest hit with caller-supplied tmax: rays whose tmax is finite go through the same kernel via stmax
+        if (stats) HIP_TRY(hipEventRecord(ev_[0], c->stream));
         if (mode == CRAY_TRACE_ANY) CRAY_TRACE_GO(true, true, (const double*)nullptr);
         else if (mode == CRAY_TRACE_ANY_TIMED) CRAY_TRACE_GO(true, false, (const double*)nullptr);
         else if (mode == CRAY_TRACE_CLOSEST) CRAY_TRACE_GO(false, true, (const double*)ps.stmax);
         else CRAY_TRACE_GO(false, false, (const double*)ps.stmax);
 #undef CRAY_TRACE_GO
     }
+    if (stats) HIP_TRY(hipEventRecord(ev_[1], c->stream));
     cray_hit* closest_out = mixed ? hits + n : hits;
     if (do_any) {
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1838,6 +1844,12 @@ extern "C" int cray_trace(cray_ctx* c, cray_scene* s, const cray_ray* rays, size
     if (stats) {
         memset(stats, 0, sizeof(*stats));
         fill_stats(h, stats);
+        float ms_ = 0.f;
+        HIP_TRY(hipEventSynchronize(ev_[1]));
+        HIP_TRY(hipEventElapsedTime(&ms_, ev_[0], ev_[1]));
+        if (mixed) { stats->trace_mixed_ms = ms_; stats->trace_mixed_launches = 1; }
+        else if (do_any) { stats->trace_any_ms = ms_; stats->trace_any_launches = 1; }
+        else { stats->trace_closest_ms = ms_; stats->trace_closest_launches = 1; }
     }
     return CRAY_OK;
 }

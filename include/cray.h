@@ -206,7 +206,8 @@ int cray_render_samples(cray_ctx* ctx, cray_scene* scene, const cray_render_para
  *   CRAY_TRACE_MIXED_TIMED                     k_trace_mixed as the frame loop launches it: every ray is traced as a shadow
  *                                              ray (with its tmax) AND as a path segment (tmax = +inf, like Ray::new) in ONE
  *                                              launch; hits[0..n) = the any-hit answers, hits[n..2n) = the closest-hit records
- * Closest-hit modes honour rays[i].tmax except the mixed one. hits: n entries (2n for the mixed mode). */
+ * Closest-hit modes honour rays[i].tmax except the mixed one. hits: n entries (2n for the mixed mode).  stats (may be NULL): the
+ * traversal counters of the instrumented modes, and the launch's time in trace_closest_ms / trace_any_ms / trace_mixed_ms. */
 enum { CRAY_TRACE_CLOSEST = 0, CRAY_TRACE_ANY = 1, CRAY_TRACE_CLOSEST_TIMED = 2, CRAY_TRACE_ANY_TIMED = 3, CRAY_TRACE_MIXED_TIMED = 4 };
 int cray_trace(cray_ctx* ctx, cray_scene* scene, const cray_ray* rays, size_t n, cray_hit* hits, int mode,
                cray_stats* stats);

@@ -60,10 +60,13 @@ def test_hybrid_traversal_is_the_reference_traversal(ctxs, name):
     assert np.array_equal(ga['hit'], oa['hit'])
     assert gast['shadow_nodes'] == oast['shadow_nodes'] and gast['shadow_prims'] == oast['shadow_prims']
     # the timed kernels (no counting) find the same hits
-    gt, _ = dev.trace(rays, timed=True)
+    gt, gtst = dev.trace(rays, timed=True)
     assert np.array_equal(gt['prim'], g['prim']) and np.array_equal(gt['t'], g['t'])
-    gat, _ = dev.trace(rays, any_hit=True, timed=True)
+    gat, gatst = dev.trace(rays, any_hit=True, timed=True)
     assert np.array_equal(gat['hit'], oa['hit'])
+    # the per-ray hook reports what its one launch took (cray.h, cray_trace)
+    assert gtst['trace_closest_ms'] > 0 and gtst['trace_closest_launches'] == 1 and gtst['trace_any_ms'] == 0
+    assert gatst['trace_any_ms'] > 0 and gatst['trace_any_launches'] == 1 and gatst['trace_closest_ms'] == 0
     dev.close()
 
 
