@@ -67,7 +67,8 @@ struct cray_ctx {
     unsigned int leaf_min = 10;    // lanes of a wave that must be at a leaf slot before the leaf step runs (mixed / any-hit launches; 0 or 1: no waiting)
     unsigned int lds_shapes = 1;   // the few sphere / disk records of a scene staged in LDS by the traversal launches (CRAY_LDS_SHAPES=0: read global memory)
     unsigned int steal = 1;   // work sharing among the lanes of a wave in the drain of the shadow-ray launches (trace_body, STEAL); CRAY_STEAL=0 turns it off
-    int trace_blocks_per_cu = 4;
+    int trace_blocks_per_cu = trace_waves(0);       // resident blocks per CU of the persistent traversal launches: f64 records (cray_device.h)
+    int trace_blocks_per_cu_hyb = trace_waves(1);   // ... certified-f32 records
     int trace32_blocks_per_cu = 4;
     int shade_blocks_per_cu = 0;   // 0: the occupancy of the instantiation that runs (launch_shade)
     // path-state pool
@@ -411,6 +412,7 @@ extern "C" int cray_ctx_create(int device_id, void* stream, cray_ctx** out) {
     c->tail_seg = (unsigned int)env_int("CRAY_TAIL_SEG", 0, 1, (int)c->tail_seg);
     c->tail_age = (unsigned int)env_int("CRAY_TAIL_AGE", 0, 255, (int)c->tail_age);
     c->trace_blocks_per_cu = env_int("CRAY_TRACE_BLOCKS_PER_CU", 1, 16, c->trace_blocks_per_cu);
+    c->trace_blocks_per_cu_hyb = env_int("CRAY_TRACE_BLOCKS_PER_CU_HYB", 1, 16, c->trace_blocks_per_cu_hyb);
     c->shade_blocks_per_cu = env_int("CRAY_SHADE_BLOCKS_PER_CU", 0, 64, c->shade_blocks_per_cu);
     c->trace32_blocks_per_cu = env_int("CRAY_TRACE32_BLOCKS_PER_CU", 1, 16, c->trace32_blocks_per_cu);
     {
@@ -1211,8 +1213,8 @@ struct ShadeLaunch<kNumShadeVariants> {
 // Counting launches exist for v 0 and 1 only; the f64 any-hit launch keeps its LDS for the work sharing.
 // deep: the context has the third stack level (a frame overflowed LDS + scratch): the instantiations that carry it, on f64 records.
 template <bool ANY, bool COUNT, class... A>
-void launch_trace(int v, bool shp, bool deep, int grid, hipStream_t st, A... a) {
-    const dim3 g(grid), b(kBlock);
+void launch_trace(int v, bool shp, bool deep, int grid, int grid_hyb, hipStream_t st, A... a) {
+    const dim3 g((!deep && v == 1) ? grid_hyb : grid), b(kBlock);   // (the certified-f32 instantiations run five blocks per CU, the others four: trace_waves)
     if (deep) { hipLaunchKernelGGL((k_trace<ANY, COUNT, 0, false, true>), g, b, 0, st, a...); return; }
     if constexpr (COUNT) {
         if (v == 1) hipLaunchKernelGGL((k_trace<ANY, true, 1>), g, b, 0, st, a...);
@@ -1225,8 +1227,8 @@ void launch_trace(int v, bool shp, bool deep, int grid, hipStream_t st, A... a) 
     }
 }
 template <class... A>
-void launch_mixed(int v, bool shp, bool tail, bool deep, int grid, hipStream_t st, A... a) {
-    const dim3 g(grid), b(kBlock);
+void launch_mixed(int v, bool shp, bool tail, bool deep, int grid, int grid_hyb, hipStream_t st, A... a) {
+    const dim3 g((!deep && v == 1) ? grid_hyb : grid), b(kBlock);
     if (deep) { hipLaunchKernelGGL((k_trace_mixed<0, false, false, true>), g, b, 0, st, a...); return; }
     // a mixed launch is launched twice when the small-launch instantiation is on (Counters::tail_rays != 0): each of the two
     // returns at once unless the launch has its size — the host does not know the queue lengths
@@ -1282,15 +1284,16 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
         unsigned int* n_next = ((b + 1) & 1) ? &ctr->n_active1 : &ctr->n_active0;
         // an upper bound of the live paths is not known on the host: size the grids for the pass
         const int g_trace = grid_for(c, n_paths, c->trace_blocks_per_cu);  // persistent: 4 blocks x 4 waves per CU at 4 waves/SIMD
+        const int g_trace_hyb = grid_for(c, n_paths, c->trace_blocks_per_cu_hyb);   // 5 x 4 with the certified-f32 records
         const int g_trace32 = grid_for(c, n_paths, c->trace32_blocks_per_cu);
 
         if (!mixed || b == 0) {
             HIP_TRY(hipMemsetAsync(&ctr->trace_head, 0, sizeof(unsigned int), st));
             if (tm) { int e = tm->begin(FAM_CLOSEST); if (e) return e; }
             const int v_closest = b == 0 ? s->use_b0 : s->use_rest;
-            if (count) launch_trace<false, true>(v_closest, shp, deep, g_trace, st, d, ps_b, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
+            if (count) launch_trace<false, true>(v_closest, shp, deep, g_trace, g_trace_hyb, st, d, ps_b, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
             else if (fast) hipLaunchKernelGGL((k_trace32<kTraceClosest>), dim3(g_trace32), dim3(kBlock), 0, st, d, ps_b, q, nq, n_paths, (const uint32_t*)nullptr, (const unsigned int*)nullptr, ctr, &ctr->trace_head, b == 0 ? c->refill_min_b0 : c->refill_min, b == 0 ? 1u : 0u);
-            else launch_trace<false, false>(v_closest, shp, deep, g_trace, st, d, ps_b, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, (b == 0 ? c->refill_min_b0 : c->refill_min) | shp_bit);
+            else launch_trace<false, false>(v_closest, shp, deep, g_trace, g_trace_hyb, st, d, ps_b, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, (b == 0 ? c->refill_min_b0 : c->refill_min) | shp_bit);
             if (tm) { int e = tm->end(); if (e) return e; }
         }
 
@@ -1307,18 +1310,18 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
             if (tm) { int e = tm->begin(FAM_MIXED); if (e) return e; }
             if (fast) hipLaunchKernelGGL((k_trace32<kTraceMixed>), dim3(g_trace32), dim3(kBlock), 0, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, 0u,
                                          (const uint32_t*)q_next, (const unsigned int*)n_next, ctr, &ctr->trace_head, c->refill_min, 0u);
-            else launch_mixed(s->use_rest, shp, c->tail_res != nullptr, deep, g_trace, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, (const uint32_t*)q_next,
+            else launch_mixed(s->use_rest, shp, c->tail_res != nullptr, deep, g_trace, g_trace_hyb, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, (const uint32_t*)q_next,
                               (const unsigned int*)n_next, ctr, &ctr->trace_head,
                               (s->use_rest ? c->refill_min_hyb | (c->refill_min_any_hyb << 16) : c->refill_min | (c->refill_min_any << 16)) | (c->leaf_min << 7) | (c->steal ? 0x8000u : 0u) | shp_bit);
             if (tm) { int e = tm->end(); if (e) return e; }
         } else {
             if (tm) { int e = tm->begin(FAM_ANY); if (e) return e; }
-            if (count) launch_trace<true, true>(s->use_rest, shp, deep, g_trace, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
+            if (count) launch_trace<true, true>(s->use_rest, shp, deep, g_trace, g_trace_hyb, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
             else if (fast) hipLaunchKernelGGL((k_trace32<kTraceAny>), dim3(g_trace32), dim3(kBlock), 0, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, 0u,
                                               (const uint32_t*)nullptr, (const unsigned int*)nullptr, ctr, &ctr->trace_head, c->refill_min, 0u);
             // (the any-hit launch of the last bounce is all drain: the f64 instantiation, which shares work between lanes, beats
             // the f32 culling there — 0.22 against 0.47 ms at an eighth of configs[2])
-            else launch_trace<true, false>((s->use_rest == 1 && c->steal) ? 0 : s->use_rest, shp, deep, g_trace, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min_any | (c->steal ? 0x8000u : 0u) | shp_bit);
+            else launch_trace<true, false>((s->use_rest == 1 && c->steal) ? 0 : s->use_rest, shp, deep, g_trace, g_trace_hyb, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min_any | (c->steal ? 0x8000u : 0u) | shp_bit);
             if (tm) { int e = tm->end(); if (e) return e; }
         }
         if (c->log_queues) {   // diagnostics only: a host round trip per bounce
@@ -1796,11 +1799,11 @@ extern "C" int cray_trace(cray_ctx* c, cray_scene* s, const cray_ray* rays, size
         HIP_TRY(hipMemcpy(&ctr->n_shadow, &cnt, sizeof(cnt), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(&ctr->n_active0, &cnt, sizeof(cnt), hipMemcpyHostToDevice));
         if (stats) HIP_TRY(hipEventRecord(ev_[0], c->stream));
-        launch_mixed(level, shp, c->tail_res != nullptr, s->needs_deep && c->deep_depth != 0, g, c->stream, s->dev, ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, (const uint32_t*)nullptr,
+        launch_mixed(level, shp, c->tail_res != nullptr, s->needs_deep && c->deep_depth != 0, g, g, c->stream, s->dev, ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, (const uint32_t*)nullptr,
                      (const unsigned int*)&ctr->n_active0, ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16) | (c->steal ? 0x8000u : 0u) | (shp ? 0x4000u : 0u) | (c->tail_seg ? 0x2000u : 0u));
     } else {
 #define CRAY_TRACE_GO(ANY_, COUNT_, TMAX_)                                                                                       \
-    launch_trace<ANY_, COUNT_>(level, shp, s->needs_deep && c->deep_depth != 0, g, c->stream, s->dev, ps, (const uint32_t*)nullptr, (const unsigned int*)nullptr, (uint32_t)n, TMAX_, ctr, \
+    launch_trace<ANY_, COUNT_>(level, shp, s->needs_deep && c->deep_depth != 0, g, g, c->stream, s->dev, ps, (const uint32_t*)nullptr, (const unsigned int*)nullptr, (uint32_t)n, TMAX_, ctr, \
                                &ctr->trace_head, c->refill_min | (c->steal ? 0x8000u : 0u) | (shp ? 0x4000u : 0u))
         // closest hit with caller-supplied tmax: rays whose tmax is finite go through the same kernel via stmax
         if (stats) HIP_TRY(hipEventRecord(ev_[0], c->stream));

@@ -37,15 +37,8 @@ constexpr int kBlock = 256;
 //               (path_integrator.rs:141-163).
 //  COUNT      : also count popped nodes / primitive tests exactly as the reference visits them.
 // ---------------------------------------------------------------------------------
-#ifndef CRAY_TRACE_WAVES
-#define CRAY_TRACE_WAVES 4
-#endif
-// CRAY_TRACE_EU(min, max): pin the waves per SIMD the register allocator plans for (experiments; default: launch bounds only)
-#ifdef CRAY_TRACE_EU_MAX
-#define CRAY_TRACE_EU __attribute__((amdgpu_waves_per_eu(CRAY_TRACE_WAVES, CRAY_TRACE_EU_MAX)))
-#else
+// (waves per SIMD of the traversal launches: trace_waves(HYB), cray_device.h)
 #define CRAY_TRACE_EU
-#endif
 //  MODE 2 (mixed): ONE launch traces the path segments of bounce b+1 (positions [0, n_closest) of a virtual queue) and
 //  the shadow rays of bounce b (the rest).  The two depend only on k_shade of bounce b, not on each other
 //  (the shadow rays add to L, the segments write hit records), and together they have one drain phase instead
@@ -150,16 +143,17 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PsArg ps_ar
     unsigned long long dg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 
-    // Traversal stack: the bottom kLdsStack entries of every lane live in LDS ([entry][thread], so a
+    constexpr int kLds = trace_lds_stack(HYB);   // stack entries per lane in LDS (cray_device.h)
+    // Traversal stack: the bottom kLds entries of every lane live in LDS ([entry][thread], so a
     // wave's access is conflict-free), deeper entries (rare) spill to scratch.  An entry is 12 B: the child reference and its
     // f64 key, or (HYB) the reference, the encoded f32 key estimate and parent | side << 31 for a later exact test.
     // (one array [entry][word][thread] — reference, f64 key as two words / HYB: key estimate, parent — so that the pop loop walks
     // it with ONE address register and immediate offsets)
-    __shared__ uint32_t lds_st[kLdsStack * 3 * kBlock];
+    __shared__ uint32_t lds_st[kLds * 3 * kBlock];
 #define CRAY_LDS_REF(i_, t_) lds_st[((i_) * 3) * kBlock + (t_)]
 #define CRAY_LDS_W0(i_, t_) lds_st[((i_) * 3 + 1) * kBlock + (t_)]
 #define CRAY_LDS_W1(i_, t_) lds_st[((i_) * 3 + 2) * kBlock + (t_)]
-    uint32_t sst[(kStackDepth - kLdsStack) * 3];   // (scratch level: the three words of an entry side by side, one address, one load)
+    uint32_t sst[(kStackDepth - kLds) * 3];   // (scratch level: the three words of an entry side by side, one address, one load)
     const unsigned int tid = threadIdx.x;
     // work sharing in the drain (STEAL): per ray that has been split — indexed by the thread that fetched it from the queue, its
     // "owner" — the number of workers still walking and whether one of them found an occluder; `steal_pair` matches the k-th idle
@@ -210,16 +204,16 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PsArg ps_ar
         } else { r_ = 0u; w0_ = 0u; w1_ = 0u; }
 #define CRAY_PUSH_W(r_, w0_, w1_)                                                          \
     do {                                                                                   \
-        if (sp < kLdsStack) { CRAY_LDS_REF(sp, tid) = (r_); CRAY_LDS_W0(sp, tid) = (w0_); CRAY_LDS_W1(sp, tid) = (w1_); sp++; } \
-        else if (sp < kStackDepth) { sst[(sp - kLdsStack) * 3] = (r_); sst[(sp - kLdsStack) * 3 + 1] = (w0_); sst[(sp - kLdsStack) * 3 + 2] = (w1_); sp++; }      \
+        if (sp < kLds) { CRAY_LDS_REF(sp, tid) = (r_); CRAY_LDS_W0(sp, tid) = (w0_); CRAY_LDS_W1(sp, tid) = (w1_); sp++; } \
+        else if (sp < kStackDepth) { sst[(sp - kLds) * 3] = (r_); sst[(sp - kLds) * 3 + 1] = (w0_); sst[(sp - kLds) * 3 + 2] = (w1_); sp++; }      \
         CRAY_DEEP_PUSH(r_, w0_, w1_)                                                       \
     } while (0)
 #define CRAY_PUSH(r_, k_) CRAY_PUSH_W(r_, (uint32_t)__double2loint(k_), (uint32_t)__double2hiint(k_))
 #define CRAY_PUSH_H(r_, kc_, par_) CRAY_PUSH_W(r_, __float_as_uint(kc_), (par_))
 #define CRAY_POP_W(r_, w0_, w1_)                                                           \
     do {                                                                                   \
-        if (sp < kLdsStack) { r_ = CRAY_LDS_REF(sp, tid); w0_ = CRAY_LDS_W0(sp, tid); w1_ = CRAY_LDS_W1(sp, tid); } \
-        else if (sp < kStackDepth) { r_ = sst[(sp - kLdsStack) * 3]; w0_ = sst[(sp - kLdsStack) * 3 + 1]; w1_ = sst[(sp - kLdsStack) * 3 + 2]; }               \
+        if (sp < kLds) { r_ = CRAY_LDS_REF(sp, tid); w0_ = CRAY_LDS_W0(sp, tid); w1_ = CRAY_LDS_W1(sp, tid); } \
+        else if (sp < kStackDepth) { r_ = sst[(sp - kLds) * 3]; w0_ = sst[(sp - kLds) * 3 + 1]; w1_ = sst[(sp - kLds) * 3 + 2]; }               \
         CRAY_DEEP_POP(r_, w0_, w1_)                                                        \
     } while (0)
     int sp = 0;
@@ -310,7 +304,7 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PsArg ps_ar
 }
 
 template <bool ANY, bool COUNT, int HYB, bool SHAPES_LDS = false, bool DEEP = false>
-__global__ void CRAY_TRACE_EU __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace(DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
+__global__ void CRAY_TRACE_EU __launch_bounds__(kBlock, trace_waves(HYB)) k_trace(DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
                                                   const unsigned int* __restrict__ n_ptr, uint32_t n_fixed,
                                                   const double* __restrict__ closest_tmax, Counters* ctr, unsigned int* work_head, unsigned int refill_min) {
     trace_body<ANY ? kTraceAny : kTraceClosest, COUNT, HYB, SHAPES_LDS, false, DEEP>(sc, ps_kernarg(), queue, n_ptr ? *n_ptr : n_fixed, nullptr, 0u, closest_tmax, ctr, work_head, refill_min);
@@ -318,7 +312,7 @@ __global__ void CRAY_TRACE_EU __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trac
 
 // shadow rays of one bounce (any_queue) + path segments of the next (closest_queue) in one persistent launch
 template <int HYB, bool SHAPES_LDS = false, bool TAIL = false, bool DEEP = false>
-__global__ void CRAY_TRACE_EU __launch_bounds__(kBlock, CRAY_TRACE_WAVES) k_trace_mixed(DevScene sc, PathState ps, const uint32_t* __restrict__ any_queue,
+__global__ void CRAY_TRACE_EU __launch_bounds__(kBlock, trace_waves(HYB)) k_trace_mixed(DevScene sc, PathState ps, const uint32_t* __restrict__ any_queue,
                                                   const unsigned int* __restrict__ n_any_ptr, const uint32_t* __restrict__ closest_queue,
                                                   const unsigned int* __restrict__ n_closest_ptr, Counters* ctr, unsigned int* work_head,
                                                   unsigned int refill_min) {
