@@ -106,7 +106,8 @@ def exchange_comm_id(backend, rank, world):
 
 
 # environment variables that select another library or other kernel instantiations / launch shapes than the profiled default
-INSTANTIATION_ENV = ('CRAY_LIB', 'CRAY_HYBRID', 'CRAY_STEAL', 'CRAY_LDS_SHAPES', 'CRAY_MIX_TRACE', 'CRAY_TAIL_RAYS', 'CRAY_SHADE_VARIANT')
+INSTANTIATION_ENV = ('CRAY_LIB', 'CRAY_HYBRID', 'CRAY_STEAL', 'CRAY_LDS_SHAPES', 'CRAY_MIX_TRACE', 'CRAY_TAIL_RAYS', 'CRAY_SHADE_VARIANT',
+                     'CRAY_TRACE_BLOCKS_PER_CU', 'CRAY_TRACE_BLOCKS_PER_CU_HYB')
 
 
 def committed_traffic(workload, lib_hash, launches_per_frame, world=1, precision='f64', path=None, records=None, environ=None):

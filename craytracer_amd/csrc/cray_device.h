@@ -37,12 +37,13 @@ constexpr uint32_t kShadeTile = CRAY_SHADE_TILE;  // paths per block-level queue
 #endif
 constexpr int kLdsStack = CRAY_LDS_STACK;  // entries per lane kept in LDS (12 B each)
 // Round 5: the launches that read the certified-f32 records run FIVE waves per SIMD.  Their loop needs 105 vector registers at four
-// waves and fits the 96 of five with no spill (bounce 0) or two (mixed); five resident blocks need a block's LDS under 32 KB, hence 9
-// stack entries per lane there (27 KB + the 2 KB of sphere / disk records).  configs[2]: bounce 0 22.0 -> 20.2 ms, mixed 107.3 -> 100.8,
-// configs[3] 745 -> 695 ms (profiles/r05_five_waves_ab.log).  The f64-record instantiations (124-126 registers) stay at four: at 96
+// waves and fits the 96 of five with no spill (bounce 0) or two (mixed); five resident blocks need a block's LDS under 32 KB, hence 10
+// stack entries per lane there (30 KB) and room for four sphere / disk records instead of eight (1 KB; cray_kernels.h).  configs[2]:
+// bounce 0 22.0 -> 19.9 ms, mixed 107.3 -> 99.1, configs[3] 745 -> 692 ms (profiles/r05_five_waves_ab.log; 9 entries + eight records:
+// mixed 100.9, 8 entries: 104-107).  The f64-record instantiations (124-126 registers) stay at four: at 96
 // registers they spill 26-46 (configs[1], which runs on them, 13.1 -> 15.3 ms).
 #ifndef CRAY_LDS_STACK_HYB
-#define CRAY_LDS_STACK_HYB 9
+#define CRAY_LDS_STACK_HYB 10
 #endif
 #ifndef CRAY_TRACE_WAVES_HYB
 #define CRAY_TRACE_WAVES_HYB 5

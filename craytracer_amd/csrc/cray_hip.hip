@@ -62,9 +62,12 @@ struct cray_ctx {
     unsigned int refill_min = 28, refill_min_b0 = 64, refill_min_any = 28;
     // the launches that read certified f32 culling refill a little earlier (their iteration is shorter, an idle lane costs relatively
     // more): 20 / 20 is 1 % faster than 28 / 28 on configs[2]; the f64 launches of configs[3] lose 2 % at 20 / 20
-    // (profiles/r04_refill_sweep_f32_culling*.log)
-    unsigned int refill_min_hyb = 20, refill_min_any_hyb = 20;
-    unsigned int leaf_min = 10;    // lanes of a wave that must be at a leaf slot before the leaf step runs (mixed / any-hit launches; 0 or 1: no waiting)
+    // (profiles/r04_refill_sweep_f32_culling*.log).  At five waves per SIMD (round 5) 24 / 24: configs[2] mixed 99.1 -> 98.3 ms, configs[3] 475.8 -> 472.8
+    // (16: 102.3, 28: 101.2 on the nine-entry layout; profiles/r05_five_waves_thresholds_ab.log)
+    unsigned int refill_min_hyb = 24, refill_min_any_hyb = 24;
+    // lanes of a wave that must be at a leaf slot before the leaf step runs (mixed / any-hit launches; 0 or 1: no waiting); 12 since the
+    // five-waves layout (10: configs[2] mixed 99.1 against 98.8, configs[3] 475.8 against 471.9; configs[1] is flat from 6 to 14)
+    unsigned int leaf_min = 12;
     unsigned int lds_shapes = 1;   // the few sphere / disk records of a scene staged in LDS by the traversal launches (CRAY_LDS_SHAPES=0: read global memory)
     unsigned int steal = 1;   // work sharing among the lanes of a wave in the drain of the shadow-ray launches (trace_body, STEAL); CRAY_STEAL=0 turns it off
     int trace_blocks_per_cu = trace_waves(0);       // resident blocks per CU of the persistent traversal launches: f64 records (cray_device.h)
@@ -1213,7 +1216,8 @@ struct ShadeLaunch<kNumShadeVariants> {
 // Counting launches exist for v 0 and 1 only; the f64 any-hit launch keeps its LDS for the work sharing.
 // deep: the context has the third stack level (a frame overflowed LDS + scratch): the instantiations that carry it, on f64 records.
 template <bool ANY, bool COUNT, class... A>
-void launch_trace(int v, bool shp, bool deep, int grid, int grid_hyb, hipStream_t st, A... a) {
+void launch_trace(int v, bool shp, bool shp_hyb, bool deep, int grid, int grid_hyb, hipStream_t st, A... a) {
+    if (v == 1) shp = shp_hyb;   // (the five-waves instantiations have room for fewer sphere / disk records in LDS: kTraceLdsShapesHyb)
     const dim3 g((!deep && v == 1) ? grid_hyb : grid), b(kBlock);   // (the certified-f32 instantiations run five blocks per CU, the others four: trace_waves)
     if (deep) { hipLaunchKernelGGL((k_trace<ANY, COUNT, 0, false, true>), g, b, 0, st, a...); return; }
     if constexpr (COUNT) {
@@ -1227,7 +1231,8 @@ void launch_trace(int v, bool shp, bool deep, int grid, int grid_hyb, hipStream_
     }
 }
 template <class... A>
-void launch_mixed(int v, bool shp, bool tail, bool deep, int grid, int grid_hyb, hipStream_t st, A... a) {
+void launch_mixed(int v, bool shp, bool shp_hyb, bool tail, bool deep, int grid, int grid_hyb, hipStream_t st, A... a) {
+    if (v == 1) shp = shp_hyb;
     const dim3 g((!deep && v == 1) ? grid_hyb : grid), b(kBlock);
     if (deep) { hipLaunchKernelGGL((k_trace_mixed<0, false, false, true>), g, b, 0, st, a...); return; }
     // a mixed launch is launched twice when the small-launch instantiation is on (Counters::tail_rays != 0): each of the two
@@ -1272,6 +1277,7 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
     const bool fast = prm.precision == CRAY_PRECISION_F32_TRAVERSAL;   // check_render_args refuses it together with counting
     const bool deep = s->needs_deep && c->deep_depth != 0;   // this scene needs the third stack level: its instantiations (f64 records) trace the pass
     const bool shp = shapes_fit_lds(c, d) && !deep;
+    const bool shp_hyb = shp && d.n_spheres + d.n_disks <= kTraceLdsShapesHyb;
     const unsigned int shp_bit = (shp ? 0x4000u : 0u) | (c->tail_seg ? 0x2000u : 0u);   // + whether small launches split segments: both ride in refill_min
     const unsigned int trace_all = prm.count_traversal == 1 ? 1u : 0u;  // 2 = count, but keep skipping zero-term shadow rays
     for (uint32_t b = 0; b < d.max_depth; b++) {
@@ -1291,9 +1297,9 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
             HIP_TRY(hipMemsetAsync(&ctr->trace_head, 0, sizeof(unsigned int), st));
             if (tm) { int e = tm->begin(FAM_CLOSEST); if (e) return e; }
             const int v_closest = b == 0 ? s->use_b0 : s->use_rest;
-            if (count) launch_trace<false, true>(v_closest, shp, deep, g_trace, g_trace_hyb, st, d, ps_b, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
+            if (count) launch_trace<false, true>(v_closest, shp, shp_hyb, deep, g_trace, g_trace_hyb, st, d, ps_b, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
             else if (fast) hipLaunchKernelGGL((k_trace32<kTraceClosest>), dim3(g_trace32), dim3(kBlock), 0, st, d, ps_b, q, nq, n_paths, (const uint32_t*)nullptr, (const unsigned int*)nullptr, ctr, &ctr->trace_head, b == 0 ? c->refill_min_b0 : c->refill_min, b == 0 ? 1u : 0u);
-            else launch_trace<false, false>(v_closest, shp, deep, g_trace, g_trace_hyb, st, d, ps_b, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, (b == 0 ? c->refill_min_b0 : c->refill_min) | shp_bit);
+            else launch_trace<false, false>(v_closest, shp, shp_hyb, deep, g_trace, g_trace_hyb, st, d, ps_b, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, (b == 0 ? c->refill_min_b0 : c->refill_min) | shp_bit);
             if (tm) { int e = tm->end(); if (e) return e; }
         }
 
@@ -1310,18 +1316,18 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
             if (tm) { int e = tm->begin(FAM_MIXED); if (e) return e; }
             if (fast) hipLaunchKernelGGL((k_trace32<kTraceMixed>), dim3(g_trace32), dim3(kBlock), 0, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, 0u,
                                          (const uint32_t*)q_next, (const unsigned int*)n_next, ctr, &ctr->trace_head, c->refill_min, 0u);
-            else launch_mixed(s->use_rest, shp, c->tail_res != nullptr, deep, g_trace, g_trace_hyb, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, (const uint32_t*)q_next,
+            else launch_mixed(s->use_rest, shp, shp_hyb, c->tail_res != nullptr, deep, g_trace, g_trace_hyb, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, (const uint32_t*)q_next,
                               (const unsigned int*)n_next, ctr, &ctr->trace_head,
                               (s->use_rest ? c->refill_min_hyb | (c->refill_min_any_hyb << 16) : c->refill_min | (c->refill_min_any << 16)) | (c->leaf_min << 7) | (c->steal ? 0x8000u : 0u) | shp_bit);
             if (tm) { int e = tm->end(); if (e) return e; }
         } else {
             if (tm) { int e = tm->begin(FAM_ANY); if (e) return e; }
-            if (count) launch_trace<true, true>(s->use_rest, shp, deep, g_trace, g_trace_hyb, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
+            if (count) launch_trace<true, true>(s->use_rest, shp, shp_hyb, deep, g_trace, g_trace_hyb, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
             else if (fast) hipLaunchKernelGGL((k_trace32<kTraceAny>), dim3(g_trace32), dim3(kBlock), 0, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, 0u,
                                               (const uint32_t*)nullptr, (const unsigned int*)nullptr, ctr, &ctr->trace_head, c->refill_min, 0u);
             // (the any-hit launch of the last bounce is all drain: the f64 instantiation, which shares work between lanes, beats
             // the f32 culling there — 0.22 against 0.47 ms at an eighth of configs[2])
-            else launch_trace<true, false>((s->use_rest == 1 && c->steal) ? 0 : s->use_rest, shp, deep, g_trace, g_trace_hyb, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min_any | (c->steal ? 0x8000u : 0u) | shp_bit);
+            else launch_trace<true, false>((s->use_rest == 1 && c->steal) ? 0 : s->use_rest, shp, shp_hyb, deep, g_trace, g_trace_hyb, st, d, ps_n, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, 0u, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min_any | (c->steal ? 0x8000u : 0u) | shp_bit);
             if (tm) { int e = tm->end(); if (e) return e; }
         }
         if (c->log_queues) {   // diagnostics only: a host round trip per bounce
@@ -1786,6 +1792,7 @@ extern "C" int cray_trace(cray_ctx* c, cray_scene* s, const cray_ray* rays, size
     const int level = (c->hybrid > 0 && s->hybrid_ok) ? c->hybrid : 0;
     if ((e = ensure_hybrid(c, s, level))) return e;
     const bool shp = shapes_fit_lds(c, s->dev);   // the timed instantiations the frame loop would launch for this scene
+    const bool shp_hyb = shp && s->dev.n_spheres + s->dev.n_disks <= kTraceLdsShapesHyb;
     hipEvent_t ev_[2] = {nullptr, nullptr};   // the launch's time for `stats` (trace_mixed_ms / trace_any_ms / trace_closest_ms)
     if (stats) { HIP_TRY(hipEventCreate(&ev_[0])); HIP_TRY(hipEventCreate(&ev_[1])); }
     struct EvFree { hipEvent_t* e; ~EvFree() { for (int i = 0; i < 2; i++) if (e[i]) (void)hipEventDestroy(e[i]); } } ev_free_{ev_};
@@ -1799,11 +1806,11 @@ extern "C" int cray_trace(cray_ctx* c, cray_scene* s, const cray_ray* rays, size
         HIP_TRY(hipMemcpy(&ctr->n_shadow, &cnt, sizeof(cnt), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(&ctr->n_active0, &cnt, sizeof(cnt), hipMemcpyHostToDevice));
         if (stats) HIP_TRY(hipEventRecord(ev_[0], c->stream));
-        launch_mixed(level, shp, c->tail_res != nullptr, s->needs_deep && c->deep_depth != 0, g, g, c->stream, s->dev, ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, (const uint32_t*)nullptr,
+        launch_mixed(level, shp, shp_hyb, c->tail_res != nullptr, s->needs_deep && c->deep_depth != 0, g, g, c->stream, s->dev, ps, (const uint32_t*)c->shadow_queue, (const unsigned int*)&ctr->n_shadow, (const uint32_t*)nullptr,
                      (const unsigned int*)&ctr->n_active0, ctr, &ctr->trace_head, c->refill_min | (c->refill_min_any << 16) | (c->steal ? 0x8000u : 0u) | (shp ? 0x4000u : 0u) | (c->tail_seg ? 0x2000u : 0u));
     } else {
 #define CRAY_TRACE_GO(ANY_, COUNT_, TMAX_)                                                                                       \
-    launch_trace<ANY_, COUNT_>(level, shp, s->needs_deep && c->deep_depth != 0, g, g, c->stream, s->dev, ps, (const uint32_t*)nullptr, (const unsigned int*)nullptr, (uint32_t)n, TMAX_, ctr, \
+    launch_trace<ANY_, COUNT_>(level, shp, shp_hyb, s->needs_deep && c->deep_depth != 0, g, g, c->stream, s->dev, ps, (const uint32_t*)nullptr, (const unsigned int*)nullptr, (uint32_t)n, TMAX_, ctr, \
                                &ctr->trace_head, c->refill_min | (c->steal ? 0x8000u : 0u) | (shp ? 0x4000u : 0u))
         // closest hit with caller-supplied tmax: rays whose tmax is finite go through the same kernel via stmax
         if (stats) HIP_TRY(hipEventRecord(ev_[0], c->stream));

@@ -45,6 +45,8 @@ constexpr int kBlock = 256;
 //  of two — the lanes of a draining any-hit launch were 84 % idle for a fifth of its iterations.
 enum { kTraceClosest = 0, kTraceAny = 1, kTraceMixed = 2 };
 constexpr uint32_t kTraceLdsShapes = 8;   // sphere + disk records (272 B each) a traversal block stages in LDS
+constexpr uint32_t kTraceLdsShapesHyb = 4;   // ... in the five-waves instantiations: five blocks of 30 KB of stack + 1 KB of these fit a CU's 160 KB
+constexpr uint32_t trace_lds_shapes(int hyb) { return hyb ? kTraceLdsShapesHyb : kTraceLdsShapes; }
 // the slab summary of a child box the timed and the counting kernels use (cray_math.h): encoded special values by default,
 // -DCRAY_KEY_PLAIN=1 for the +-inf form (A/B builds)
 #ifdef CRAY_KEY_PLAIN
@@ -164,10 +166,10 @@ __device__ __forceinline__ void trace_body(const DevScene& sc, const PsArg ps_ar
     // would otherwise make the whole wave wait for a second, dependent fetch from global memory inside the iteration
     // (CRAY_TRACE_DIAG, profiles/r04_experiments.md: k_trace_mixed 137.0 -> 131.5 ms on f64 records, 131.9 -> 128.9 with f32 culling).
     // Its own instantiation: through one generic pointer for both cases the scenes that do NOT fit paid 9 % (flat loads).
-    __shared__ double lds_shapes[SHAPES_LDS ? kTraceLdsShapes * (sizeof(cray_xf_shape) / 8) : 1];
+    __shared__ double lds_shapes[SHAPES_LDS ? trace_lds_shapes(HYB) * (sizeof(cray_xf_shape) / 8) : 1];
     const cray_xf_shape* spheres = sc.spheres;
     const cray_xf_shape* disks = sc.disks;
-    // (the host launches this instantiation only when 0 < n_spheres + n_disks <= kTraceLdsShapes, and sets bit 14 of refill_min.
+    // (the host launches this instantiation only when 0 < n_spheres + n_disks <= trace_lds_shapes(HYB), and sets bit 14 of refill_min.
     // For the f64 instantiations the bit is tested, so that the compiler cannot prove where the records are: with pointers it
     // KNOWS to be LDS k_trace_mixed<0> came out with two registers spilled in its loop and the gain was gone — 138.0 ms against
     // 131.4 with this test and 137.1 without any staging, profiles/r04_lds_shapes_ab.log.)
