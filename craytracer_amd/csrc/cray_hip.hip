@@ -1291,6 +1291,9 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
         // an upper bound of the live paths is not known on the host: size the grids for the pass
         const int g_trace = grid_for(c, n_paths, c->trace_blocks_per_cu);  // persistent: 4 blocks x 4 waves per CU at 4 waves/SIMD
         const int g_trace_hyb = grid_for(c, n_paths, c->trace_blocks_per_cu_hyb);   // 5 x 4 with the certified-f32 records
+        // (a SMALL bounce-0 launch — a rank's share of a sharded frame — is mostly ramp and drain, and a fifth block per CU only adds waves to
+        // both: an eighth of configs[2], 16.6 M paths: 3.04 ms on four blocks, 3.36 on five; a quarter: 5.8 either way; the whole frame 21.9 / 19.9)
+        const int g_b0_hyb = (n_paths < ((size_t)24 << 20) && c->trace_blocks_per_cu_hyb > c->trace_blocks_per_cu) ? grid_for(c, n_paths, c->trace_blocks_per_cu) : g_trace_hyb;
         const int g_trace32 = grid_for(c, n_paths, c->trace32_blocks_per_cu);
 
         if (!mixed || b == 0) {
@@ -1299,7 +1302,7 @@ int run_pass(cray_ctx* c, cray_scene* s, const cray_render_params& prm, const Pa
             const int v_closest = b == 0 ? s->use_b0 : s->use_rest;
             if (count) launch_trace<false, true>(v_closest, shp, shp_hyb, deep, g_trace, g_trace_hyb, st, d, ps_b, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, c->refill_min);
             else if (fast) hipLaunchKernelGGL((k_trace32<kTraceClosest>), dim3(g_trace32), dim3(kBlock), 0, st, d, ps_b, q, nq, n_paths, (const uint32_t*)nullptr, (const unsigned int*)nullptr, ctr, &ctr->trace_head, b == 0 ? c->refill_min_b0 : c->refill_min, b == 0 ? 1u : 0u);
-            else launch_trace<false, false>(v_closest, shp, shp_hyb, deep, g_trace, g_trace_hyb, st, d, ps_b, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, (b == 0 ? c->refill_min_b0 : c->refill_min) | shp_bit);
+            else launch_trace<false, false>(v_closest, shp, shp_hyb, deep, g_trace, b == 0 ? g_b0_hyb : g_trace_hyb, st, d, ps_b, q, nq, n_paths, (const double*)nullptr, ctr, &ctr->trace_head, (b == 0 ? c->refill_min_b0 : c->refill_min) | shp_bit);
             if (tm) { int e = tm->end(); if (e) return e; }
         }
 
