@@ -165,10 +165,12 @@ def test_pinned_records_are_what_a_call_reads():
 
 @pytest.mark.parametrize('records', ['0', '1'])
 def test_shape_records_in_lds_or_in_global_memory_same_film(records):
-    """The traversal blocks stage a scene's sphere / disk records in LDS when there are at most eight of them (their own
-    instantiations); a scene with more, or CRAY_LDS_SHAPES=0, reads them from global memory.  Same hits either way:
-    films of both contexts equal the oracle's, on a scene that fits (two disks, one sphere) and on one that does not (twelve
-    spheres and a disk light), with f64 records and with certified f32 culling."""
+    """The traversal blocks stage a scene's sphere / disk records in LDS when there are at most eight of them (four in the
+    five-waves instantiations of the certified-f32 records; their own instantiations); a scene with more, or
+    CRAY_LDS_SHAPES=0, reads them from global memory.  Same hits either way:
+    films of both contexts equal the oracle's, on a scene that fits (two disks, one sphere), on one between the two capacities
+    (two disks, four spheres) and on one that does not fit either (twelve spheres and a disk light), with f64 records and with
+    certified f32 culling."""
     import os
     from craytracer_amd import scene as S, scenes
     old = {k: os.environ.get(k) for k in ('CRAY_LDS_SHAPES', 'CRAY_HYBRID')}
@@ -193,7 +195,9 @@ def test_shape_records_in_lds_or_in_global_memory_same_film(records):
     for i in range(12):
         prims.append(S.Primitive.new(S.Shape.new_sphere((-5.5 + i, 0.45 + 0.3 * (i % 3), 2.0 + 0.5 * (i % 4)), 0.45), glass if i % 2 else matte))
     many = S.Scene(5, 8, cam, [S.Light.Infinite(S.Color(0.05, 0.07, 0.1))], prims)
-    for sc in (scenes.simple(64, 48, 8, 4), many):
+    # six records: staged by the f64-record instantiations (room for eight), read from global memory by the five-waves ones (room for four)
+    some = S.Scene(5, 8, cam, [S.Light.Infinite(S.Color(0.05, 0.07, 0.1))], prims[:6])
+    for sc in (scenes.simple(64, 48, 8, 4), some, many):
         ref, _ = ol.OracleScene(sc).render(seed=6)
         for ctx in (staged, plain):
             dev = ctx.upload(backend.HostScene(sc))
